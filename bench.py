@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+A "step" is one pass of the hot path (one plan_fft'd `fft(out, x)` call) over one batch of
+synthetic complex64 input that is already resident in HBM.  At N=1 the workload is
+BASELINE.json configs[1]: 100k x 1024 1-D C2C fp32 with the user radix list [2]
+("radix-2 Stockham").  For N>1 every rank owns its own 100k x 1024 slab (weak scaling, no
+data-path collective: rows are independent transforms); value = rows of all ranks * FLOPs / the
+max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      HBM roofline of the dominant kernel; `achieved` = algorithmic bytes per launch
+                (16 B per complex element: one 8-B read + one 8-B write) divided by
+                the average launch duration measured with HIP events on the launch stream inside
+                libmifft (mifft_time_exec).
+  cpu_baseline  the CPU oracle (restatement of the reference's multi-threaded CPU path) timed on
+                this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+WORKLOADS = {
+    # name: (shape without the complex dim, user bases, BASELINE.json config index)
+    "1d_100kx1024_radix2": ((100000, 1024), [[2]], 1),
+    "1d_500kx93_radix31x3": ((500000, 93), [[31, 3]], 2),
+    "1d_500kx128": ((500000, 128), None, 0),
+    "2d_100x640x480": ((100, 640, 480), None, 3),
+    "3d_10x128x128x128": ((10, 128, 128, 128), None, 4),
+}
+DEFAULT_WORKLOAD = "1d_100kx1024_radix2"
+
+
+def flops_5nlogn(shape):
+    n = 1
+    for d in shape[1:]:
+        n *= d
+    return 5.0 * n * math.log2(n) * shape[0]
+
+
+def cpu_baseline(shape, bases, budget_s=12.0):
+    """Oracle timed on a bounded sample (leading-batch subset) of the workload."""
+    import numpy as np
+    from oracle import mifft_oracle as O
+
+    cores = O.num_procs()
+    rng = np.random.default_rng(1234)
+    per = int(np.prod(shape[1:]))
+
+    def run(b):
+        x = rng.standard_normal((b,) + tuple(shape[1:]) + (2,), dtype=np.float32)
+        out = np.empty_like(x)
+        plan = O.plan_fft(np.float32, np.float32, x.shape, x.shape, bases=bases, default_target="gpu")
+        O.fft(out, x, plan=plan, cpu_workers=cores)  # warm-up (page faults, thread pool)
+        t = time.perf_counter()
+        O.fft(out, x, plan=plan, cpu_workers=cores)
+        return time.perf_counter() - t
+
+    b0 = max(1, min(shape[0], (1 << 21) // per))
+    t0 = max(run(b0), 1e-4)
+    b1 = int(max(b0, min(shape[0], b0 * (budget_s / 2) / t0, (1 << 28) // per)))
+    t1 = run(b1) if b1 > b0 else t0
+    gflops = flops_5nlogn((b1,) + tuple(shape[1:])) / t1 / 1e9
+    return {
+        "value": round(gflops, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
+        "sample": f"{b1} of {shape[0]} leading-batch entries of the same shape, all {cores} host threads, "
+                  f"oracle/libmifft_oracle.so (C++ restatement of the reference CPU path), {t1 * 1e3:.1f} ms",
+        "ms_per_transform": round(t1 * 1e3 / b1, 6),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--faithful", action="store_true", help="force the literal stage-per-pass kernel family")
+    args = ap.parse_args()
+
+    import torch
+
+    import hackathon_fft_amd as mf
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: libmifft has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+
+    shape, bases, cfg_idx = WORKLOADS[args.workload]
+    dev = torch.device("cuda", local_rank)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(tuple(shape) + (2,), generator=gen, device=dev, dtype=torch.float32)
+    out = torch.empty_like(x)
+    ctx = mf.DeviceContext(local_rank)
+    plan = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, bases=bases, ctx=ctx,
+                       faithful_stages=args.faithful)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mf.fft(out, x, ctx, plan=plan)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mf.fft(out, x, ctx, plan=plan)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-level time: HIP events on the launch stream, inside the library
+    launch_ms = mf.time_fft(out, x, plan=plan, iters=max(10, min(args.steps, 200)), ctx=ctx)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        total_flops = flops_5nlogn(shape) * n_gpus
+        value = total_flops / (ms_per_step * 1e-3) / 1e9
+        elems = 1
+        for d in shape:
+            elems *= d
+        algo_bytes = 16.0 * elems  # per launch sequence on ONE gpu
+        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
+        kernels = [plan.kernel_name(d) for d in range(len(shape) - 1)]
+        result = {
+            "metric": "C2C GFLOP/s (5Nlog2N) + ms/transform, 100k×1024 fp32 @1/2/4/8 MI355X",
+            "value": round(value, 2),
+            "unit": "GFLOP/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "us_per_transform": round(ms_per_step * 1e3 / shape[0], 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload,
+                "baseline_config_index": cfg_idx,
+                "shape_per_gpu": list(shape) + [2],
+                "bases": bases if bases is not None else "reference gpu default",
+                "stages": [plan.stages(d) for d in range(len(shape) - 1)],
+                "kernels": kernels,
+                "launches_per_step": plan.num_launches,
+                "parallelism": f"batch-sharded x{n_gpus}, no data-path collective",
+                "input": "complex64 N(0,1), seed 1234+rank, resident in HBM",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": "+".join(kernels),
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "launch_ms_hip_events": round(launch_ms, 5),
+            },
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(shape, bases)
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

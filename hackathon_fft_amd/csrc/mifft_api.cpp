@@ -1,0 +1,335 @@
+// mifft_api.cpp -- the C ABI of libmifft (see include/mifft.h).
+//
+// Host scheduler replacing _run_gpu_nd_fft (fft/fft/_ndim_fft_gpu.mojo:462-642):
+// the contiguous (last) dimension is transformed first, reading `x` and writing
+// `out`; every earlier dimension is then transformed IN PLACE on `out` by a
+// strided tile kernel.  The reference's transpose launches and scratch buffer
+// do not exist here: d launches instead of d + 2(d-1).
+#include <cmath>
+#include <cstring>
+
+#include "mifft_internal.h"
+
+namespace mifft {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int hip_error(hipError_t e, const char* what) {
+    g_last_error = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+    return MIFFT_ERR_HIP;
+}
+
+size_t Plan::in_elem_bytes() const { return dtype_size(in_dtype) * (size_t)in_components; }
+size_t Plan::out_elem_bytes() const { return dtype_size(out_dtype) * 2; }
+
+// W_N^n = exp(-+ 2*pi*i*n/N), evaluated in long double and rounded once to the
+// output dtype (reference formula: fft/fft/_utils.mojo:63-104, which rounds theta
+// to the working dtype first; see DESIGN.md "numerics").
+template <typename T>
+static void fill_twiddles(std::vector<T>& tab, int64_t N, bool inverse) {
+    tab.resize((size_t)2 * N);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int64_t n = 0; n < N; ++n) {
+        // exact octant values where they exist
+        long double re, im;
+        const int64_t n8 = 8 * n;
+        if (n8 % N == 0 && ((n8 / N) % 2) == 0) {
+            switch ((n8 / N) / 2) {
+                case 0: re = 1, im = 0; break;
+                case 1: re = 0, im = -1; break;
+                case 2: re = -1, im = 0; break;
+                default: re = 0, im = 1; break;
+            }
+        } else {
+            long double th = -two_pi * (long double)n / (long double)N;
+            re = cosl(th);
+            im = sinl(th);
+        }
+        if (inverse) im = -im;
+        tab[2 * n] = (T)re;
+        tab[2 * n + 1] = (T)im;
+    }
+}
+
+static void free_plan_device(Plan& p) {
+    for (auto& ps : p.passes) {
+        if (ps.d_twiddle) (void)hipFree(ps.d_twiddle);
+        if (ps.d_aux) (void)hipFree(ps.d_aux);
+        ps.d_twiddle = ps.d_aux = nullptr;
+    }
+}
+
+static int device_count_quiet() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+}  // namespace mifft
+
+using namespace mifft;
+
+extern "C" {
+
+const char* mifft_last_error(void) { return g_last_error.c_str(); }
+
+const char* mifft_status_string(int s) {
+    switch (s) {
+        case MIFFT_OK: return "ok";
+        case MIFFT_ERR_BAD_RANK: return "bad rank";
+        case MIFFT_ERR_BAD_DIM: return "bad dimension";
+        case MIFFT_ERR_BAD_COMPONENTS: return "bad component count";
+        case MIFFT_ERR_BAD_DTYPE: return "bad dtype";
+        case MIFFT_ERR_BAD_BASES: return "bases do not factor the length";
+        case MIFFT_ERR_BASE_ONE: return "base 1";
+        case MIFFT_ERR_NO_BASES: return "no bases";
+        case MIFFT_ERR_BAD_BATCH: return "bad batch";
+        case MIFFT_ERR_TOO_LARGE: return "dimension too large";
+        case MIFFT_ERR_NO_DEVICE: return "no device";
+        case MIFFT_ERR_HIP: return "hip error";
+        case MIFFT_ERR_NULL: return "null argument";
+        case MIFFT_ERR_ALIAS: return "x and out overlap";
+        case MIFFT_ERR_BUFFER_TOO_SMALL: return "buffer too small";
+    }
+    return "unknown";
+}
+
+int mifft_version(void) { return MIFFT_VERSION_MAJOR * 100 + MIFFT_VERSION_MINOR; }
+
+int mifft_device_count(void) { return device_count_quiet(); }
+
+int mifft_ordered_bases(uint32_t length, const uint32_t* bases, int nbases, uint32_t* ordered_out, int capacity) {
+    std::vector<uint64_t> user;
+    for (int i = 0; i < nbases; ++i) user.push_back(bases[i]);
+    std::vector<uint32_t> ord, proc;
+    std::string err;
+    int rc = plan_ordered_bases(length, user, ord, proc, err);
+    if (rc) return set_error(rc, err);
+    for (size_t i = 0; i < ord.size() && (int)i < capacity; ++i) ordered_out[i] = ord[i];
+    return (int)ord.size();
+}
+
+int mifft_estimate_bases(uint32_t length, int target_gpu, uint32_t* bases_out, int capacity) {
+    if (length < 2) return set_error(MIFFT_ERR_BAD_DIM, "length must be >= 2");
+    auto b = plan_estimate_bases(length, target_gpu != 0);
+    for (size_t i = 0; i < b.size() && (int)i < capacity; ++i) bases_out[i] = (uint32_t)b[i];
+    return (int)b.size();
+}
+
+int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_dtype, int ndim,
+                      const int64_t* dims, int64_t batch, int in_components, int inverse,
+                      const uint32_t* bases_flat, const int32_t* bases_len, uint32_t flags) {
+    if (!out_plan) return set_error(MIFFT_ERR_NULL, "out_plan is NULL");
+    *out_plan = nullptr;
+    // ---- validation = _check_layout_conditions_nd (fft/fft/fft.mojo:20-46) ----
+    if (ndim < 1 || ndim > MIFFT_MAX_DIMS)
+        return set_error(MIFFT_ERR_BAD_RANK, "The rank should be bigger than 2 (1..3 transformed dims supported)");
+    if (!dims) return set_error(MIFFT_ERR_NULL, "dims is NULL");
+    if (in_components < 1 || in_components > 2)
+        return set_error(MIFFT_ERR_BAD_COMPONENTS, "The last dimension of in_layout should be 1 or 2");
+    if (out_dtype != MIFFT_F32 && out_dtype != MIFFT_F64)
+        return set_error(MIFFT_ERR_BAD_DTYPE, "out_dtype must be floating point");
+    if (in_dtype < MIFFT_F32 || in_dtype > MIFFT_I32) return set_error(MIFFT_ERR_BAD_DTYPE, "unsupported in_dtype");
+    if (batch < 0) return set_error(MIFFT_ERR_BAD_BATCH, "batch must be >= 0");
+    for (int i = 0; i < ndim; ++i)
+        if (dims[i] < 2) return set_error(MIFFT_ERR_BAD_DIM, "no inner dimension should be of size 1");
+    if ((bases_flat == nullptr) != (bases_len == nullptr))
+        return set_error(MIFFT_ERR_NULL, "bases_flat and bases_len must both be given or both be NULL");
+
+    mifft_plan* h = new mifft_plan();
+    Plan& p = h->p;
+    p.device = device;
+    p.in_dtype = in_dtype;
+    p.out_dtype = out_dtype;
+    p.ndim = ndim;
+    p.batch = batch;
+    p.in_components = in_components;
+    p.inverse = inverse ? 1 : 0;
+    p.flags = flags;
+    p.prod = 1;
+    for (int i = 0; i < ndim; ++i) {
+        p.dims[i] = dims[i];
+        p.prod *= dims[i];
+    }
+
+    // ---- radix planning per dimension (host only; errors before any device use) ----
+    std::vector<std::vector<uint32_t>> ordered(ndim), processed(ndim);
+    const uint32_t* bp = bases_flat;
+    for (int i = 0; i < ndim; ++i) {
+        std::vector<uint64_t> user;
+        if (bases_flat) {
+            if (bases_len[i] < 0) {
+                delete h;
+                return set_error(MIFFT_ERR_NO_BASES, "negative bases_len");
+            }
+            for (int k = 0; k < bases_len[i]; ++k) user.push_back(*bp++);
+        } else {
+            user = plan_estimate_bases((uint64_t)dims[i], /*gpu_target=*/true);
+        }
+        std::string err;
+        int rc = plan_ordered_bases((uint64_t)dims[i], user, ordered[i], processed[i], err);
+        if (rc) {
+            delete h;
+            return set_error(rc, err);
+        }
+    }
+
+    // ---- device ----
+    const int ndev = device_count_quiet();
+    if (device < 0 || device >= ndev) {
+        delete h;
+        return set_error(MIFFT_ERR_NO_DEVICE,
+                         "libmifft has no CPU path: device " + std::to_string(device) + " is not a usable HIP device (" +
+                             std::to_string(ndev) + " visible)");
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        delete h;
+        return hip_error(e, "hipSetDevice");
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) p.num_cus = prop.multiProcessorCount;
+
+    // ---- passes in execution order: last dimension first ----
+    for (int i = ndim - 1; i >= 0; --i) {
+        DimPass ps;
+        ps.dim_index = i;
+        ps.N = dims[i];
+        ps.inner = 1;
+        for (int k = i + 1; k < ndim; ++k) ps.inner *= dims[k];
+        ps.outer = 1;
+        for (int k = 0; k < i; ++k) ps.outer *= dims[k];
+        ps.radices = ordered[i];
+        ps.processed = processed[i];
+        ps.first = i == ndim - 1;
+        bool ok = false;
+        if (!(flags & MIFFT_FLAG_FAITHFUL_STAGES)) ok = select_fast(p, ps);
+        if (!ok) {
+            std::string why;
+            ok = select_generic(p, ps, why);
+            if (!ok) {
+                free_plan_device(p);
+                delete h;
+                return set_error(MIFFT_ERR_TOO_LARGE, why);
+            }
+        }
+        // twiddle table of the dimension
+        if (out_dtype == MIFFT_F32) {
+            std::vector<float> tab;
+            fill_twiddles(tab, ps.N, inverse != 0);
+            e = hipMalloc(&ps.d_twiddle, tab.size() * sizeof(float));
+            if (e == hipSuccess) e = hipMemcpy(ps.d_twiddle, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+        } else {
+            std::vector<double> tab;
+            fill_twiddles(tab, ps.N, inverse != 0);
+            e = hipMalloc(&ps.d_twiddle, tab.size() * sizeof(double));
+            if (e == hipSuccess) e = hipMemcpy(ps.d_twiddle, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+        }
+        p.passes.push_back(ps);
+        if (e != hipSuccess) {
+            free_plan_device(p);
+            delete h;
+            return hip_error(e, "twiddle table upload");
+        }
+    }
+    *out_plan = h;
+    return MIFFT_OK;
+}
+
+int mifft_exec_batch(const mifft_plan* plan, const void* x, void* out, int64_t first, int64_t count,
+                     void* stream) {
+    if (!plan) return set_error(MIFFT_ERR_NULL, "plan is NULL");
+    const Plan& p = plan->p;
+    if (first < 0 || count < 0 || first + count > p.batch)
+        return set_error(MIFFT_ERR_BAD_BATCH, "batch range out of bounds");
+    if (count == 0) return MIFFT_OK;
+    if (!x || !out) return set_error(MIFFT_ERR_NULL, "x or out is NULL");
+    const size_t in_row = (size_t)p.prod * p.in_elem_bytes(), out_row = (size_t)p.prod * p.out_elem_bytes();
+    const char* xb = (const char*)x + (size_t)first * in_row;
+    char* ob = (char*)out + (size_t)first * out_row;
+    // out-of-place contract (reference: first stage reads x, all writes go elsewhere)
+    if (xb < ob + (size_t)count * out_row && ob < xb + (size_t)count * in_row)
+        return set_error(MIFFT_ERR_ALIAS, "x and out must not overlap");
+    MIFFT_HIP_TRY(hipSetDevice(p.device));
+    hipStream_t s = (hipStream_t)stream;
+    for (const DimPass& ps : p.passes) {
+        int rc = ps.launch(p, ps, ps.first ? (const void*)xb : (const void*)ob, ob, count, s);
+        if (rc) return rc;
+    }
+    return MIFFT_OK;
+}
+
+int mifft_exec(const mifft_plan* plan, const void* x, void* out, void* stream) {
+    if (!plan) return set_error(MIFFT_ERR_NULL, "plan is NULL");
+    return mifft_exec_batch(plan, x, out, 0, plan->p.batch, stream);
+}
+
+void mifft_plan_destroy(mifft_plan* plan) {
+    if (!plan) return;
+    (void)hipSetDevice(plan->p.device);
+    free_plan_device(plan->p);
+    delete plan;
+}
+
+int mifft_plan_stages(const mifft_plan* plan, int dim, uint32_t* radices_out, int capacity) {
+    if (!plan) return set_error(MIFFT_ERR_NULL, "plan is NULL");
+    for (const DimPass& ps : plan->p.passes)
+        if (ps.dim_index == dim) {
+            for (size_t i = 0; i < ps.radices.size() && (int)i < capacity; ++i) radices_out[i] = ps.radices[i];
+            return (int)ps.radices.size();
+        }
+    return set_error(MIFFT_ERR_BAD_RANK, "dim out of range");
+}
+
+const char* mifft_plan_kernel_name(const mifft_plan* plan, int dim) {
+    if (!plan) return "";
+    for (const DimPass& ps : plan->p.passes)
+        if (ps.dim_index == dim) return ps.kernel_name;
+    return "";
+}
+
+int mifft_plan_num_launches(const mifft_plan* plan) {
+    if (!plan) return set_error(MIFFT_ERR_NULL, "plan is NULL");
+    return (int)plan->p.passes.size();
+}
+
+size_t mifft_plan_in_bytes(const mifft_plan* plan) {
+    return plan ? (size_t)plan->p.batch * plan->p.prod * plan->p.in_elem_bytes() : 0;
+}
+
+size_t mifft_plan_out_bytes(const mifft_plan* plan) {
+    return plan ? (size_t)plan->p.batch * plan->p.prod * plan->p.out_elem_bytes() : 0;
+}
+
+int mifft_time_exec(const mifft_plan* plan, const void* x, void* out, void* stream, int iters, float* ms_out) {
+    if (!plan || !ms_out) return set_error(MIFFT_ERR_NULL, "plan or ms_out is NULL");
+    if (iters < 1) iters = 1;
+    MIFFT_HIP_TRY(hipSetDevice(plan->p.device));
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    MIFFT_HIP_TRY(hipEventCreate(&e0));
+    MIFFT_HIP_TRY(hipEventCreate(&e1));
+    int rc = MIFFT_OK;
+    hipError_t he = hipEventRecord(e0, s);
+    for (int i = 0; i < iters && rc == MIFFT_OK && he == hipSuccess; ++i) rc = mifft_exec(plan, x, out, stream);
+    if (he == hipSuccess) he = hipEventRecord(e1, s);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (he != hipSuccess) return hip_error(he, "mifft_time_exec events");
+    *ms_out = ms / (float)iters;
+    return MIFFT_OK;
+}
+
+}  // extern "C"

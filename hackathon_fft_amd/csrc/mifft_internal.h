@@ -1,0 +1,98 @@
+// mifft_internal.h -- plan structures shared by the C-ABI layer and the kernel
+// launchers of libmifft (MI355X / gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mifft.h"
+
+namespace mifft {
+
+// ---- host-only planner (planner.cpp) --------------------------------------
+// Independent implementation of the reference's radix planning rules:
+//   _times_divisible_by / _build_ordered_bases   fft/fft/_utils.mojo:125-183
+//   _get_ordered_bases_processed_list            fft/fft/_utils.mojo:186-221
+//   _estimate_best_bases                         fft/fft/fft.mojo:49-104
+int plan_ordered_bases(uint64_t length, const std::vector<uint64_t>& user, std::vector<uint32_t>& ordered,
+                       std::vector<uint32_t>& processed, std::string& err);
+std::vector<uint64_t> plan_estimate_bases(uint64_t length, bool gpu_target);
+
+// ---- error plumbing (mifft_api.cpp) ----------------------------------------
+int set_error(int code, const std::string& msg);
+int hip_error(hipError_t e, const char* what);
+#define MIFFT_HIP_TRY(expr)                                   \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return ::mifft::hip_error(_e, #expr); \
+    } while (0)
+
+// ---- plan -------------------------------------------------------------------
+struct Plan;
+struct DimPass;
+
+// Launches the 1-D transforms of one dimension for `count` leading-batch
+// entries.  `in` is x (only for the last dimension, which runs first) or `out`
+// itself (in-place tile passes for the strided dimensions).
+typedef int (*LaunchFn)(const Plan& plan, const DimPass& pass, const void* in, void* out, int64_t count,
+                        hipStream_t stream);
+
+struct DimPass {
+    int dim_index = 0;
+    int64_t N = 0;        // transform length
+    int64_t inner = 1;    // element stride of this dim = prod(dims after it)
+    int64_t outer = 1;    // prod(dims before it)   (times batch at launch)
+    std::vector<uint32_t> radices;    // descending stage radices (reference order)
+    std::vector<uint32_t> processed;  // prefix products P_b
+    void* d_twiddle = nullptr;        // device table W_N^n, n in [0,N), complex<out dtype>
+    void* d_aux = nullptr;            // kernel-family specific device table (may be null)
+    const char* kernel_name = "none";
+    LaunchFn launch = nullptr;
+    // geometry chosen by the kernel family at plan time
+    int tile = 1;          // transforms per workgroup tile
+    int ld = 0;            // LDS leading dimension (complex elements)
+    int threads = 256;
+    size_t lds_bytes = 0;
+    bool first = false;    // reads x (with in_dtype / in_components) instead of out
+};
+
+struct Plan {
+    int device = 0;
+    int in_dtype = MIFFT_F32, out_dtype = MIFFT_F32;
+    int ndim = 1;
+    int64_t dims[MIFFT_MAX_DIMS] = {0, 0, 0};
+    int64_t batch = 0;
+    int64_t prod = 1;
+    int in_components = 2;
+    int inverse = 0;
+    uint32_t flags = 0;
+    int num_cus = 256;
+    std::vector<DimPass> passes;  // in execution order: last dim first
+    size_t in_elem_bytes() const;
+    size_t out_elem_bytes() const;  // bytes of one complex output element
+};
+
+// kernel families; each returns true and fills pass.launch/tile/... when it
+// accepts the (plan, pass) pair.
+bool select_generic(const Plan& plan, DimPass& pass, std::string& why_not);
+bool select_fast(const Plan& plan, DimPass& pass);
+
+inline size_t dtype_size(int dt) {
+    switch (dt) {
+        case MIFFT_F32: return 4;
+        case MIFFT_F64: return 8;
+        case MIFFT_U8: return 1;
+        case MIFFT_I32: return 4;
+    }
+    return 0;
+}
+
+}  // namespace mifft
+
+// the opaque C handle
+struct mifft_plan {
+    mifft::Plan p;
+};

@@ -1,0 +1,83 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# tolerance of the reference's own tests (fft/tests.mojo:40-41)
+REF_ATOL, REF_RTOL = 1e-2, 1e-5
+# BASELINE.json north_star: <= 1e-5 relative error vs the reference CPU path,
+# measured per transform as ||y - y_ref||_2 / ||y_ref||_2 ("Tolerance definition")
+REL_L2_TOL_F32 = 1e-5
+REL_L2_TOL_F64 = 1e-12
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_1d():
+    with open(os.path.join(GOLDEN, "fft_1d.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_2d():
+    with open(os.path.join(GOLDEN, "fft_2d.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_3d():
+    with open(os.path.join(GOLDEN, "fft_3d.json")) as f:
+        return json.load(f)
+
+
+def load_matrix():
+    with open(os.path.join(GOLDEN, "fft_1d.json")) as f:
+        d = json.load(f)
+    return [(m["n"], tuple(m["bases"])) for m in d["matrix"]]
+
+
+def rel_l2(y, ref):
+    """max over transforms (leading axis) of ||y - ref||_2 / ||ref||_2; inputs interleaved (.., 2)."""
+    y = np.asarray(y, dtype=np.float64).reshape(y.shape[0], -1)
+    ref = np.asarray(ref, dtype=np.float64).reshape(ref.shape[0], -1)
+    num = np.linalg.norm(y - ref, axis=1)
+    den = np.linalg.norm(ref, axis=1)
+    den[den == 0] = 1.0
+    return float((num / den).max())
+
+
+def to_complex(a):
+    a = np.asarray(a)
+    return a[..., 0].astype(np.float64) + 1j * a[..., 1].astype(np.float64)
+
+
+def from_complex(c, dtype):
+    return np.stack([c.real, c.imag], axis=-1).astype(dtype)

@@ -1,0 +1,94 @@
+"""The C-ABI shared library: loads, exports every symbol include/mifft.h declares, validates
+arguments on the host, and refuses to run without a HIP device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import hackathon_fft_amd as mf
+from hackathon_fft_amd import _lib
+from conftest import ROOT
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "mifft.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mifft_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_functions()
+    assert len(declared) >= 16
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/mifft.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_version_and_strings():
+    L = _lib.lib()
+    assert L.mifft_version() == 1
+    assert L.mifft_status_string(-5) == b"bases do not factor the length"
+
+
+def _create(device, dims, batch=4, in_dtype=0, out_dtype=0, comps=2, bases=None):
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    c_dims = (ctypes.c_int64 * len(dims))(*dims)
+    if bases is None:
+        flat, lens = None, None
+    else:
+        f = [b for bs in bases for b in bs]
+        flat = (ctypes.c_uint32 * max(1, len(f)))(*f)
+        lens = (ctypes.c_int32 * len(dims))(*[len(bs) for bs in bases])
+    rc = L.mifft_plan_create(ctypes.byref(h), device, in_dtype, out_dtype, len(dims), c_dims, batch, comps, 0,
+                             flat, lens, 0)
+    return rc, h
+
+
+@pytest.mark.parametrize("kwargs,status", [
+    (dict(dims=[]), -1),
+    (dict(dims=[4, 4, 4, 4]), -1),
+    (dict(dims=[1]), -2),
+    (dict(dims=[8, 1]), -2),
+    (dict(dims=[8], comps=3), -3),
+    (dict(dims=[8], out_dtype=2), -4),
+    (dict(dims=[8], in_dtype=9), -4),
+    (dict(dims=[8], batch=-1), -8),
+    (dict(dims=[32], bases=[[4, 2]]), -5),
+    (dict(dims=[8], bases=[[1, 8]]), -6),
+    (dict(dims=[8], bases=[[]]), -7),
+    (dict(dims=[2 * 101]), -5),
+])
+def test_plan_validation_happens_on_the_host(kwargs, status):
+    rc, h = _create(0, **kwargs)
+    assert rc == status and not h.value
+    assert _lib.lib().mifft_last_error()
+
+
+def test_no_cpu_fallback():
+    # device -1 is never valid; with no GPU in this container device 0 is refused as well
+    rc, h = _create(-1, [8])
+    assert rc == -10 and not h.value
+    if _lib.lib().mifft_device_count() == 0:
+        rc, h = _create(0, [8])
+        assert rc == -10 and not h.value
+        with pytest.raises(mf.MifftError) as e:
+            mf.DeviceContext()
+        assert e.value.status == -10
+
+
+def test_python_layout_checks_mirror_reference():
+    with pytest.raises(mf.MifftError):
+        mf.estimate_best_bases_nd((4, 2), (4, 2))              # rank <= 2
+    with pytest.raises(mf.MifftError):
+        mf.estimate_best_bases_nd((4, 8, 3), (4, 8, 2))        # C_in not in {1,2}
+    with pytest.raises(mf.MifftError):
+        mf.estimate_best_bases_nd((4, 8, 2), (4, 8, 1))        # C_out != 2
+    with pytest.raises(mf.MifftError):
+        mf.estimate_best_bases_nd((4, 8, 2), (4, 9, 2))        # leading dims differ
+    with pytest.raises(mf.MifftError):
+        mf.estimate_best_bases_nd((4, 1, 8, 2), (4, 1, 8, 2))  # inner dim of size 1
+    assert mf.estimate_best_bases_nd((10, 640, 480, 2), (10, 640, 480, 2)) == [
+        [5, 2, 2, 2, 2, 2, 2, 2], [5, 3, 2, 2, 2, 2, 2]]

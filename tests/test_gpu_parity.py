@@ -1,0 +1,230 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, the reference's
+golden vectors, and size-independent properties at the BASELINE sizes.
+
+Tolerances:
+  * golden vectors: the reference's own atol=1e-2 / rtol=1e-5 (fft/tests.mojo:40-41);
+  * vs the oracle (fp32): per-transform ||y - y_ref||_2 / ||y_ref||_2 <= 1e-5
+    (BASELINE.json north_star); fp64: <= 1e-12.
+"""
+import numpy as np
+import pytest
+import torch
+
+import hackathon_fft_amd as mf
+from conftest import (REF_ATOL, REF_RTOL, REL_L2_TOL_F32, REL_L2_TOL_F64, from_complex, load_matrix, rel_l2,
+                      to_complex)
+from oracle import mifft_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TDT = {np.float32: torch.float32, np.float64: torch.float64, np.uint8: torch.uint8, np.int32: torch.int32}
+
+
+def gpu_fft(x_np, *, bases=None, inverse=False, out_dtype=np.float64, faithful=False, first=0, count=None):
+    """Run one transform through plan_fft / fft with NaN-prefilled output (fft/tests.mojo:219-222)."""
+    x = torch.from_numpy(np.ascontiguousarray(x_np)).to(DEV)
+    x_before = x.clone()
+    out_shape = tuple(x.shape[:-1]) + (2,)
+    out = torch.full(out_shape, float("nan"), dtype=TDT[out_dtype], device=DEV)
+    with mf.DeviceContext(0) as ctx:
+        plan = mf.plan_fft(x.dtype, TDT[out_dtype], tuple(x.shape), out_shape, bases=bases, inverse=inverse,
+                           faithful_stages=faithful, ctx=ctx)
+        mf.fft(out, x, ctx, plan=plan, first=first, count=count)
+        ctx.synchronize()
+    assert torch.equal(x, x_before), "x must never be written"
+    return out.cpu().numpy(), plan
+
+
+@pytest.mark.parametrize("faithful", [True, False])
+@pytest.mark.parametrize("n,bases", load_matrix())
+def test_reference_matrix_forward_real_fp64(golden_1d, n, bases, faithful):
+    pairs = golden_1d["values"][str(n)]
+    x = np.array([p["x"] for p in pairs], dtype=np.float64).reshape(len(pairs), n, 1)
+    out, plan = gpu_fft(x, bases=[list(bases)], faithful=faithful)
+    assert not np.isnan(out).any(), "every output element must be written"
+    np.testing.assert_allclose(out, np.array([p["X"] for p in pairs]), atol=REF_ATOL, rtol=REF_RTOL)
+    assert rel_l2(out, O.fftn(x, bases=[list(bases)])) < REL_L2_TOL_F64
+    assert plan.stages(0) == O.ordered_bases(n, bases)
+
+
+@pytest.mark.parametrize("n,bases", load_matrix())
+def test_reference_matrix_inverse_complex_fp64(golden_1d, n, bases):
+    pairs = golden_1d["values"][str(n)]
+    spectrum = np.array([p["X"] for p in pairs], dtype=np.float64)
+    series = np.array([p["x"] for p in pairs], dtype=np.float64)
+    out, _ = gpu_fft(spectrum, bases=[list(bases)], inverse=True, faithful=True)
+    np.testing.assert_allclose(out[..., 0], series, atol=REF_ATOL, rtol=REF_RTOL)
+    np.testing.assert_allclose(out[..., 1], 0, atol=REF_ATOL, rtol=REF_RTOL)
+    assert rel_l2(out, O.fftn(spectrum, inverse=True, bases=[list(bases)])) < 1e-11
+
+
+@pytest.mark.parametrize("n,bases", load_matrix()[::3])
+def test_reference_matrix_fp32(golden_1d, n, bases):
+    pairs = golden_1d["values"][str(n)]
+    x = np.array([p["x"] for p in pairs], dtype=np.float32).reshape(len(pairs), n, 1)
+    for faithful in (True, False):
+        out, _ = gpu_fft(x, bases=[list(bases)], out_dtype=np.float32, faithful=faithful)
+        np.testing.assert_allclose(out, np.array([p["X"] for p in pairs]), atol=REF_ATOL, rtol=REF_RTOL)
+        assert rel_l2(out, O.fftn(x, bases=[list(bases)])) < REL_L2_TOL_F32
+
+
+@pytest.mark.parametrize("faithful", [True, False])
+@pytest.mark.parametrize("which", ["2d", "3d"])
+def test_nd_uint8_to_f64(golden_2d, golden_3d, which, faithful):
+    g = golden_2d if which == "2d" else golden_3d
+    x = np.array(g["x"], dtype=np.uint8)[None, ..., None]
+    out, plan = gpu_fft(x, faithful=faithful)
+    assert not np.isnan(out).any()
+    np.testing.assert_allclose(out, np.array(g["X_flat"]).reshape(out.shape), atol=REF_ATOL, rtol=REF_RTOL)
+    assert rel_l2(out, O.fftn(x, out_dtype=np.float64)) < REL_L2_TOL_F64
+    assert plan.num_launches == len(g["shape"])  # no transpose launches (reference: d + 2(d-1))
+    back, _ = gpu_fft(out, inverse=True, faithful=faithful)
+    np.testing.assert_allclose(back[..., 0], x[..., 0], atol=1e-9)
+
+
+# (shape, user bases) -- BASELINE.json configs at sizes the oracle finishes in seconds
+BASELINE_CASES = [
+    ((64, 128), None),
+    ((37, 1024), [[2]]),
+    ((301, 93), [[31, 3]]),
+    ((2, 640, 480), None),
+    ((2, 128, 128, 128), None),
+    ((3, 64, 64, 64), None),
+    ((5, 16, 12, 10), None),
+    ((130, 480), None),
+    ((90, 640), None),
+    ((7, 4096), None),
+    ((1, 2), None),
+    ((3, 97), None),
+]
+
+
+@pytest.mark.parametrize("faithful", [True, False])
+@pytest.mark.parametrize("shape,bases", BASELINE_CASES)
+def test_c2c_fp32_vs_oracle(shape, bases, faithful):
+    rng = np.random.default_rng(1234)
+    x = rng.standard_normal(shape + (2,)).astype(np.float32)
+    out, plan = gpu_fft(x, bases=bases, out_dtype=np.float32, faithful=faithful)
+    assert not np.isnan(out).any()
+    ref = O.fftn(x, bases=bases)
+    err = rel_l2(out, ref)
+    assert err < REL_L2_TOL_F32, (shape, [plan.kernel_name(d) for d in range(len(shape) - 1)], err)
+    truth = np.fft.fftn(to_complex(x), axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
+    back, _ = gpu_fft(out, bases=bases, inverse=True, out_dtype=np.float32, faithful=faithful)
+    assert rel_l2(back, x) < REL_L2_TOL_F32
+
+
+@pytest.mark.parametrize("shape", [(9, 1024), (11, 93), (2, 40, 30), (1, 8, 6, 10)])
+def test_c2c_fp64_vs_oracle(shape):
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal(shape + (2,))
+    for faithful in (True, False):
+        out, _ = gpu_fft(x, faithful=faithful)
+        assert rel_l2(out, O.fftn(x)) < REL_L2_TOL_F64
+
+
+@pytest.mark.parametrize("in_dtype", [np.float32, np.float64, np.uint8, np.int32])
+@pytest.mark.parametrize("comps", [1, 2])
+def test_input_dtypes_and_real_input(in_dtype, comps):
+    rng = np.random.default_rng(5)
+    x = (rng.integers(0, 200, size=(4, 12, 20, comps))).astype(in_dtype)
+    out, _ = gpu_fft(x, out_dtype=np.float32)
+    ref = O.fftn(x, out_dtype=np.float32)
+    assert rel_l2(out, ref) < REL_L2_TOL_F32
+
+
+def test_batch_range_and_untouched_rows():
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((10, 1024, 2)).astype(np.float32)
+    full, _ = gpu_fft(x, out_dtype=np.float32)
+    part, _ = gpu_fft(x, out_dtype=np.float32, first=3, count=4)
+    assert np.isnan(part[:3]).all() and np.isnan(part[7:]).all()
+    assert np.array_equal(part[3:7], full[3:7])  # a slab equals the same rows of the whole batch, bit for bit
+    empty, _ = gpu_fft(x, out_dtype=np.float32, first=0, count=0)
+    assert np.isnan(empty).all()
+
+
+def test_errors_from_the_device_side_of_the_boundary():
+    x = torch.zeros((2, 8, 2), device=DEV)
+    plan = mf.plan_fft(torch.float32, torch.float32, (2, 8, 2), (2, 8, 2))
+    with pytest.raises(mf.MifftError) as e:
+        mf.fft(x, x, plan=plan)           # aliasing: the reference is out-of-place
+    assert e.value.status == -13
+    with pytest.raises(mf.MifftError):
+        mf.fft(torch.zeros((2, 8, 2)), x, plan=plan)   # host tensor
+    with pytest.raises(mf.MifftError):
+        mf.fft(torch.zeros((2, 9, 2), device=DEV), x, plan=plan)
+    with pytest.raises(mf.MifftError) as e:
+        mf.plan_fft(torch.float32, torch.float32, (1, 1 << 20, 2), (1, 1 << 20, 2), bases=[[2]])
+    assert e.value.status == -9            # does not fit one workgroup's LDS (reference: unsupported too)
+
+
+def test_convenience_wrappers():
+    rng = np.random.default_rng(2)
+    xc = torch.from_numpy(rng.standard_normal((3, 16, 12)) + 1j * rng.standard_normal((3, 16, 12))).to(DEV)
+    y = mf.fftn(xc, radices=[[4, 2], [3, 2]])
+    np.testing.assert_allclose(y.cpu().numpy(), np.fft.fftn(xc.cpu().numpy(), axes=(1, 2)), atol=1e-10)
+    np.testing.assert_allclose(mf.ifftn(y).cpu().numpy(), xc.cpu().numpy(), atol=1e-12)
+    xr = torch.from_numpy(rng.standard_normal((2, 30))).to(DEV)
+    full = mf.rfftn(xr)
+    np.testing.assert_allclose(to_complex(full.cpu().numpy()), np.fft.fft(xr.cpu().numpy(), axis=1), atol=1e-12)
+
+
+# ---- full BASELINE sizes: properties that need no CPU reference ----------------------------
+
+FULL_SIZES = [
+    ((100000, 1024), [[2]]),
+    ((500000, 93), [[31, 3]]),
+    ((500000, 128), None),
+    ((100, 640, 480), None),
+    ((10, 128, 128, 128), None),
+]
+
+
+@pytest.mark.parametrize("shape,bases", FULL_SIZES)
+def test_full_size_properties(shape, bases):
+    g = torch.Generator(device=DEV).manual_seed(1234)
+    x = torch.randn(shape + (2,), generator=g, device=DEV, dtype=torch.float32)
+    out = torch.full_like(x, float("nan"))
+    ctx = mf.DeviceContext(0)
+    fwd = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, bases=bases, ctx=ctx)
+    inv = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, bases=bases, inverse=True, ctx=ctx)
+    mf.fft(out, x, ctx, plan=fwd)
+    ctx.synchronize()
+    assert not torch.isnan(out).any()
+    n_per = int(np.prod(shape[1:]))
+    b = shape[0]
+    # Parseval per transform: sum |X|^2 = N sum |x|^2
+    ex = (x.double() ** 2).reshape(b, -1).sum(1)
+    eX = (out.double() ** 2).reshape(b, -1).sum(1)
+    assert ((eX / (n_per * ex) - 1).abs().max().item()) < 1e-5
+    # DC bin = sum of the inputs
+    dc = out.reshape(b, n_per, 2)[:, 0, :].double()
+    s = x.double().reshape(b, n_per, 2).sum(1)
+    assert ((dc - s).norm(dim=1) / (ex.sqrt() * np.sqrt(n_per))).max().item() < 1e-5
+    # encode -> decode round trip
+    back = torch.full_like(x, float("nan"))
+    mf.fft(back, out, ctx, plan=inv)
+    ctx.synchronize()
+    num = (back.double() - x.double()).reshape(b, -1).norm(dim=1)
+    assert (num / ex.sqrt()).max().item() < 1e-5
+    # spot-check transforms against the oracle (first, last and one in the middle)
+    small = O.plan_fft(np.float32, np.float32, (1,) + shape[1:] + (2,), (1,) + shape[1:] + (2,), bases=bases)
+    for idx in (0, b // 2, b - 1):
+        xi = x[idx:idx + 1].cpu().numpy()
+        ref = np.empty_like(xi)
+        O.fft(ref, xi, plan=small)
+        assert rel_l2(out[idx:idx + 1].cpu().numpy(), ref) < REL_L2_TOL_F32
+    # linearity on a slab: F(a*x + y) = a*F(x) + F(y)
+    k = min(b, 64)
+    y = torch.randn((k,) + tuple(x.shape[1:]), generator=g, device=DEV, dtype=torch.float32)
+    lin_plan = mf.plan_fft(torch.float32, torch.float32, y.shape, y.shape, bases=bases, ctx=ctx)
+    fy, fz = torch.empty_like(y), torch.empty_like(y)
+    z = (0.5 * x[:k] + y).contiguous()
+    mf.fft(fy, y, ctx, plan=lin_plan)
+    mf.fft(fz, z, ctx, plan=lin_plan)
+    ctx.synchronize()
+    lhs, rhs = fz.double(), 0.5 * out[:k].double() + fy.double()
+    assert ((lhs - rhs).reshape(k, -1).norm(dim=1) / rhs.reshape(k, -1).norm(dim=1)).max().item() < 1e-5
