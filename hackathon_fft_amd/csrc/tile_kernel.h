@@ -1,0 +1,397 @@
+// tile_kernel.h -- register-butterfly Stockham tile kernel template for MI355X (gfx950).
+//
+// One kernel per dimension.  A workgroup owns a TILE of independent transforms of one
+// dimension; the tile lives in LDS for the whole transform and HBM is touched exactly once
+// for reading and once for writing:
+//
+//   pass 0      : work item = one radix-R0 butterfly; its R0 inputs come straight from HBM
+//                 (lanes -> consecutive elements, so every wave instruction reads whole
+//                 contiguous runs), DFT_R0 in registers, results scattered into LDS at the
+//                 Stockham-permuted positions        dst[q*P*R + s*P + p]
+//   pass 1..k-2 : LDS -> registers (stride N/R gather, conflict-free), twiddle W_{P R}^{j p},
+//                 DFT_R in registers, registers -> LDS (same buffer, after a barrier)
+//   pass k-1    : as above, but the results go straight to HBM in natural order
+//                 (for the last stage q = 0, so lanes again write contiguous runs).
+//
+// The user's radix stages (reference: one LDS pass + barrier per stage, one thread per
+// output, fft/fft/_ndim_fft_gpu.mojo:359-386) are fused into 2-4 composite passes, e.g.
+// 1024 = 2^10 -> 16 * 8 * 8: two LDS exchanges instead of ten.  Work items of a pass are
+// flattened over the whole workgroup, so radices that do not divide the thread count
+// (31 * 3, 10 * 6 * 8) keep every lane busy.
+//
+// Strided dimensions (COLS): the tile is TILE adjacent columns, LDS layout [n][column];
+// lanes run along the columns, so HBM runs are TILE*8 bytes and LDS accesses are
+// contiguous by construction.  The transform is in place -- this replaces the reference's
+// transpose kernel + scratch buffer (fft/fft/_ndim_fft_gpu.mojo:210-276, :185).
+//
+// Twiddles: W_N^n from the plan's fp64-accurate table.  Per-thread twiddles are loop
+// invariant over tiles, so a persistent workgroup keeps them in registers (TWMODE 1) or in a
+// compact conflict-free LDS table [pass][j][p] (TWMODE 2); TWMODE 0 reads the global table.
+// Inverse: conj(F(conj x)) * 1/N with the forward butterflies (bit-identical to conjugated
+// twiddles), reference semantics fft/fft/_utils.mojo:101-104, fft/fft/_fft.mojo:292-294.
+#pragma once
+
+#include "fft_radix.h"
+
+namespace mifft {
+
+struct TileParams {
+    const void* in;
+    void* out;
+    const void* tw;  // cpx<T>[N], conjugated when the plan is an inverse plan
+    long long n_tiles;
+    long long n_rows;           // ROWS
+    long long inner;            // COLS
+    long long tiles_per_outer;  // COLS
+    int inverse;
+    double scale;  // 1/N for inverse
+};
+
+constexpr int ilog2_ce(int v) {
+    int l = 0;
+    while ((1 << (l + 1)) <= v) ++l;
+    return l;
+}
+constexpr bool is_pow2_ce(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
+
+template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
+          bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0>
+struct TileCfg {
+    using T = T_;
+    static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
+    static constexpr bool COLS = COLS_, FIRST_DIRECT = FIRST_DIRECT_, LAST_DIRECT = LAST_DIRECT_;
+    static constexpr bool PREFETCH = PREFETCH_ && FIRST_DIRECT_;
+    static constexpr int LD = N_ + ROWPAD_;  // ROWS: LDS pitch of one transform
+    static constexpr int R(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : i == 2 ? R2_ : R3_; }
+    static constexpr int P(int i) {
+        int p = 1;
+        for (int k = 0; k < i; ++k) p *= R(k);
+        return p;
+    }
+    static constexpr int NB(int i) { return N / R(i); }
+    static constexpr int ITEMS(int i) { return NB(i) * TILE; }
+    static constexpr int IPT(int i) { return (ITEMS(i) + THREADS - 1) / THREADS; }
+    static constexpr int TW_OFF(int i) {  // register twiddles of passes 1..i-1 precede pass i
+        int o = 0;
+        for (int k = 1; k < i; ++k) o += IPT(k) * (R(k) - 1);
+        return o;
+    }
+    static constexpr int TW_TOTAL = TW_OFF(NP_);
+    static constexpr int TWL_OFF(int i) {  // compact LDS table [pass][j-1][p]
+        int o = 0;
+        for (int k = 1; k < i; ++k) o += P(k) * (R(k) - 1);
+        return o;
+    }
+    static constexpr int TWL_TOTAL = TWMODE_ == TW_LDS ? TWL_OFF(NP_) : 0;
+    static constexpr int DATA_ELEMS = COLS_ ? N_ * TILE_ : LD * TILE_;
+    static constexpr size_t LDS_BYTES = (size_t)(DATA_ELEMS + TWL_TOTAL) * 2 * sizeof(T_);
+    static_assert(P(NP_) == N_, "radices must multiply to N");
+};
+
+// XOR swizzle of the in-row index for the exchange written by pass E (power-of-two rows
+// only): the 16 lanes of a ds_write_b64 group own 16 butterflies whose outputs are P*R
+// elements apart; fold the low butterfly bits into the bank-selecting low 4 index bits.
+template <class C, int E>
+MIFFT_DEV int swz(int n) {
+    if constexpr (!C::COLS && is_pow2_ce(C::N) && E >= 0 && E < C::NP - 1) {
+        constexpr int a = ilog2_ce(C::P(E)), c = ilog2_ce(C::P(E) * C::R(E));
+        constexpr int c4 = c < 4 ? c : 4, hi = c > 4 ? c : 4, nb = c4 - a;
+        if constexpr (nb > 0 && (1 << hi) < C::N) {
+            return n ^ (((n >> hi) & ((1 << nb) - 1)) << a);
+        } else {
+            return n;
+        }
+    } else {
+        return n;
+    }
+}
+
+template <class C, int E>
+MIFFT_DEV int lds_index(int c, int n) {
+    if constexpr (C::COLS)
+        return n * C::TILE + c;
+    else
+        return c * C::LD + swz<C, E>(n);
+}
+
+template <class C>
+MIFFT_DEV long long gaddr(const TileParams& p, long long base, int c, int n) {
+    if constexpr (C::COLS)
+        return base + (long long)n * p.inner + c;
+    else
+        return base + (long long)c * C::N + n;
+}
+
+template <class C, int I>
+MIFFT_DEV void item_decode(int id, int& c, int& b) {
+    if constexpr (C::COLS) {
+        b = id / C::TILE;
+        c = id - b * C::TILE;
+    } else {
+        c = id / C::NB(I);
+        b = id - c * C::NB(I);
+    }
+}
+
+template <class C>
+MIFFT_DEV void tile_geom(const TileParams& p, long long t, long long& base, int& nv) {
+    if constexpr (C::COLS) {
+        const long long o = t / p.tiles_per_outer;
+        const long long c0 = (t - o * p.tiles_per_outer) * C::TILE;
+        const long long left = p.inner - c0;
+        nv = (int)(left < C::TILE ? left : C::TILE);
+        base = o * (long long)C::N * p.inner + c0;
+    } else {
+        const long long r0 = t * C::TILE;
+        const long long left = p.n_rows - r0;
+        nv = (int)(left < C::TILE ? left : C::TILE);
+        base = r0 * C::N;
+    }
+}
+
+template <class C, int I>
+MIFFT_DEV void preload_tw(cpx<typename C::T>* twr, const cpx<typename C::T>* tw, int tid, int inverse) {
+    if constexpr (I < C::NP) {
+        constexpr int R = C::R(I), P = C::P(I), RATIO = C::N / (P * R);
+#pragma unroll
+        for (int k = 0; k < C::IPT(I); ++k) {
+            int id = tid + k * C::THREADS, c, b;
+            if (id >= C::ITEMS(I)) id = 0;
+            item_decode<C, I>(id, c, b);
+            const int pp = b % P;
+#pragma unroll
+            for (int j = 1; j < R; ++j) {
+                cpx<typename C::T> w = tw[j * pp * RATIO];
+                if (inverse) w.y = -w.y;  // plan table is conjugated for inverse plans; we need W forward
+                twr[C::TW_OFF(I) + k * (R - 1) + (j - 1)] = w;
+            }
+        }
+        preload_tw<C, I + 1>(twr, tw, tid, inverse);
+    }
+}
+
+template <class C, int I>
+MIFFT_DEV void fill_lds_tw(cpx<typename C::T>* ltw, const cpx<typename C::T>* tw, int tid, int inverse) {
+    if constexpr (I < C::NP) {
+        constexpr int R = C::R(I), P = C::P(I), RATIO = C::N / (P * R);
+        for (int e = tid; e < P * (R - 1); e += C::THREADS) {
+            const int j = e / P + 1, pp = e - (j - 1) * P;
+            cpx<typename C::T> w = tw[j * pp * RATIO];
+            if (inverse) w.y = -w.y;
+            ltw[C::TWL_OFF(I) + e] = w;
+        }
+        fill_lds_tw<C, I + 1>(ltw, tw, tid, inverse);
+    }
+}
+
+// gather the pass-0 inputs of tile (base, nv) from HBM into registers
+template <class C>
+MIFFT_DEV void load_pass0(const TileParams& p, cpx<typename C::T> (*v)[C::R(0)], long long base, int nv, int tid) {
+    using T = typename C::T;
+    using V = cpx<T>;
+    constexpr int R = C::R(0), NB = C::NB(0), IPT = C::IPT(0);
+    constexpr bool EXACT = C::ITEMS(0) % C::THREADS == 0;
+    const V* gin = (const V*)p.in;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int id = tid + k * C::THREADS;
+        if (EXACT || id < C::ITEMS(0)) {
+            int c, b;
+            item_decode<C, 0>(id, c, b);
+            const bool ok = c < nv;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                V x = {(T)0, (T)0};
+                if (ok) x = gin[gaddr<C>(p, base, c, b + j * NB)];
+                v[k][j] = x;
+            }
+        }
+    }
+}
+
+template <class C, int I>
+MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<typename C::T>* twr,
+                        cpx<typename C::T> (*pre)[C::R(0)], long long base, int nv, int tid) {
+    if constexpr (I < C::NP) {
+        using T = typename C::T;
+        using V = cpx<T>;
+        constexpr int R = C::R(I), P = C::P(I), NB = C::NB(I), IPT = C::IPT(I), RATIO = C::N / (P * R);
+        constexpr bool EXACT = C::ITEMS(I) % C::THREADS == 0;
+        constexpr bool SRC_GLOBAL = (I == 0) && C::FIRST_DIRECT;
+        constexpr bool DST_GLOBAL = (I == C::NP - 1) && C::LAST_DIRECT;
+        V v[IPT][R];
+        V* gout = (V*)p.out;
+        const V* ltw = lds + C::DATA_ELEMS;
+
+        // ---- gather the R inputs of every butterfly this thread owns ----
+        if constexpr (SRC_GLOBAL) {
+            if constexpr (C::PREFETCH) {
+#pragma unroll
+                for (int k = 0; k < IPT; ++k)
+#pragma unroll
+                    for (int j = 0; j < R; ++j) v[k][j] = pre[k][j];
+            } else {
+                load_pass0<C>(p, v, base, nv, tid);
+            }
+            if (p.inverse) {
+#pragma unroll
+                for (int k = 0; k < IPT; ++k)
+#pragma unroll
+                    for (int j = 0; j < R; ++j) v[k][j].y = -v[k][j].y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const int id = tid + k * C::THREADS;
+                if (EXACT || id < C::ITEMS(I)) {
+                    int c, b;
+                    item_decode<C, I>(id, c, b);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) v[k][j] = lds[lds_index<C, I - 1>(c, b + j * NB)];
+                    if constexpr (I > 0) {
+                        const int pp = b % P;
+#pragma unroll
+                        for (int j = 1; j < R; ++j) {
+                            V w;
+                            if constexpr (C::TWMODE == TW_REG) {
+                                w = twr[C::TW_OFF(I) + k * (R - 1) + (j - 1)];
+                            } else if constexpr (C::TWMODE == TW_LDS) {
+                                w = ltw[C::TWL_OFF(I) + (j - 1) * P + pp];
+                            } else {
+                                w = ((const V*)p.tw)[j * pp * RATIO];
+                                if (p.inverse) w.y = -w.y;
+                            }
+                            v[k][j] = cmul(v[k][j], w);
+                        }
+                    }
+                }
+            }
+            // in-place LDS buffer: every read of this pass completes before any later write (this
+            // pass's scatter, or pass 0 of the NEXT tile when this pass stores to HBM)
+            __syncthreads();
+        }
+
+        // ---- butterflies + Stockham scatter ----
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int id = tid + k * C::THREADS;
+            if (EXACT || id < C::ITEMS(I)) {
+                int c, b;
+                item_decode<C, I>(id, c, b);
+                Dft<R, T, 1>::run(v[k]);
+                const int q = b / P, pp = b - q * P;
+                const int o0 = q * P * R + pp;
+                if constexpr (DST_GLOBAL) {
+                    if (c < nv) {
+#pragma unroll
+                        for (int s = 0; s < R; ++s) {
+                            V y = v[k][s];
+                            if (p.inverse) {
+                                y.x *= (T)p.scale;
+                                y.y *= -(T)p.scale;
+                            }
+                            gout[gaddr<C>(p, base, c, o0 + s * P)] = y;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < R; ++s) lds[lds_index<C, I>(c, o0 + s * P)] = v[k][s];
+                }
+            }
+        }
+        if constexpr (!DST_GLOBAL) __syncthreads();
+        run_pass<C, I + 1>(p, lds, twr, pre, base, nv, tid);
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TileParams p) {
+    using T = typename C::T;
+    using V = cpx<T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V* lds = (V*)smem;
+    const int tid = threadIdx.x;
+    V twr[(C::TWMODE == TW_REG && C::TW_TOTAL > 0) ? C::TW_TOTAL : 1];
+    if constexpr (C::TWMODE == TW_REG) preload_tw<C, 1>(twr, (const V*)p.tw, tid, p.inverse);
+    if constexpr (C::TWMODE == TW_LDS) {
+        fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, tid, p.inverse);
+        __syncthreads();
+    }
+
+    V pre[C::PREFETCH ? C::IPT(0) : 1][C::R(0)];
+    long long t = blockIdx.x;
+    if constexpr (C::PREFETCH) {
+        if (t < p.n_tiles) {
+            long long base;
+            int nv;
+            tile_geom<C>(p, t, base, nv);
+            load_pass0<C>(p, pre, base, nv, tid);
+        }
+    }
+    for (; t < p.n_tiles; t += gridDim.x) {
+        long long base;
+        int nv;
+        tile_geom<C>(p, t, base, nv);
+        V cur[C::PREFETCH ? C::IPT(0) : 1][C::R(0)];
+        if constexpr (C::PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < C::IPT(0); ++k)
+#pragma unroll
+                for (int j = 0; j < C::R(0); ++j) cur[k][j] = pre[k][j];
+            const long long tn = t + gridDim.x;
+            if (tn < p.n_tiles) {  // issue the next tile's HBM reads before this tile's arithmetic
+                long long nbase;
+                int nnv;
+                tile_geom<C>(p, tn, nbase, nnv);
+                load_pass0<C>(p, pre, nbase, nnv, tid);
+            }
+        }
+        if constexpr (!C::FIRST_DIRECT) {
+            // flat, fully coalesced HBM -> LDS copy of the tile (rows need not be 16-B aligned: N = 93)
+            static_assert(!C::COLS || C::FIRST_DIRECT, "column tiles always load directly");
+            const V* gin = (const V*)p.in;
+            const int total = nv * C::N;
+            for (int f = tid; f < total; f += C::THREADS) {
+                const int c = f / C::N, n = f - c * C::N;
+                V x = gin[base + f];
+                if (p.inverse) x.y = -x.y;
+                lds[lds_index<C, -1>(c, n)] = x;
+            }
+            __syncthreads();
+        }
+        run_pass<C, 0>(p, lds, twr, cur, base, nv, tid);
+        if constexpr (!C::LAST_DIRECT) {
+            static_assert(!C::COLS || C::LAST_DIRECT, "column tiles always store directly");
+            V* gout = (V*)p.out;
+            const int total = nv * C::N;
+            for (int f = tid; f < total; f += C::THREADS) {
+                const int c = f / C::N, n = f - c * C::N;
+                V y = lds[lds_index<C, C::NP - 1>(c, n)];
+                if (p.inverse) {
+                    y.x *= (T)p.scale;
+                    y.y *= -(T)p.scale;
+                }
+                gout[base + f] = y;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// persistent grid: enough workgroups to fill every CU to its LDS / wave limit
+template <class C>
+inline long long tile_grid(int num_cus, long long n_tiles, int wg_per_cu_override = 0) {
+    long long per_cu = (160 * 1024) / (long long)(C::LDS_BYTES ? C::LDS_BYTES : 1);
+    const long long wave_limit = 2048 / C::THREADS;
+    if (per_cu > wave_limit) per_cu = wave_limit;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    if (wg_per_cu_override > 0) per_cu = wg_per_cu_override;
+    long long grid = (long long)num_cus * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    return grid < 1 ? 1 : grid;
+}
+
+}  // namespace mifft

@@ -1,0 +1,280 @@
+// tune_tile.hip -- times tile_kernel<> variants against each other on one device, in one
+// process, interleaved (guide rule 24), and checks every variant's output against the first
+// variant of its group.  Development tool only; not part of libmifft.
+//
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DGROUP=<n> -o tune_tile tune_tile.hip && ./tune_tile
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../hackathon_fft_amd/csrc/tile_kernel.h"
+
+using namespace mifft;
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+struct Variant {
+    std::string name;
+    std::function<void(const void*, void*, const void*, long long /*batch*/, long long /*outer*/, long long /*inner*/)> run;
+    size_t lds;
+};
+
+static int g_cus = 256;
+static int g_wg_override = 0;
+
+template <class C>
+Variant make(const char* name) {
+    Variant v;
+    v.name = name;
+    v.lds = C::LDS_BYTES;
+    v.run = [](const void* in, void* out, const void* tw, long long batch, long long outer, long long inner) {
+        TileParams tp{};
+        tp.in = in;
+        tp.out = out;
+        tp.tw = tw;
+        tp.inverse = 0;
+        tp.scale = 1.0;
+        if (C::COLS) {
+            tp.inner = inner;
+            tp.tiles_per_outer = (inner + C::TILE - 1) / C::TILE;
+            tp.n_tiles = batch * outer * tp.tiles_per_outer;
+        } else {
+            tp.n_rows = batch * outer;
+            tp.inner = 1;
+            tp.tiles_per_outer = 1;
+            tp.n_tiles = (tp.n_rows + C::TILE - 1) / C::TILE;
+        }
+        auto k = tile_kernel<C>;
+        static bool set = false;
+        if (!set && C::LDS_BYTES > 64 * 1024) {
+            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+            set = true;
+        }
+        long long grid = tile_grid<C>(g_cus, tp.n_tiles, g_wg_override);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), C::LDS_BYTES, 0, tp);
+    };
+    return v;
+}
+
+#define V(NAME, ...) make<TileCfg<__VA_ARGS__>>(NAME)
+
+int main(int argc, char** argv) {
+    if (argc > 1) g_wg_override = atoi(argv[1]);
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    g_cus = prop.multiProcessorCount;
+
+#if GROUP == 1  // ---- config 2: 100k x 1024 rows ----
+    const long long batch = 100000, outer = 1, inner = 1;
+    const int N = 1024;
+    std::vector<Variant> vs = {
+        //              T      N    NP R0 R1 R2 R3 TILE THR COLS  FD    LD    TWMODE   MINW PF
+        V("16x8x8 t4 reg w1", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 1, false),
+        V("16x8x8 t4 reg w2", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, false),
+        V("16x8x8 t4 reg w3", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 3, false),
+        V("16x8x8 t4 reg w4", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 4, false),
+        V("16x8x8 t4 glb w4", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_GLOBAL, 4, false),
+        V("16x8x8 t4 lds w4", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        V("16x8x8 t4 lds w3", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 3, false),
+        V("16x8x8 t4 reg w2 pf", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
+        V("16x8x8 t4 reg w3 pf", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 3, true),
+        V("16x8x8 t4 lds w3 pf", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 3, true),
+        V("16x8x8 t4 lds w4 pf", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, true),
+        V("16x8x8 t1 reg w2", float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_REG, 2, false),
+        V("16x8x8 t1 reg w3", float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_REG, 3, false),
+        V("16x8x8 t1 lds w4", float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_LDS, 4, false),
+        V("16x8x8 t1 reg w3 pf", float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_REG, 3, true),
+        V("16x8x8 t1 lds w4 pf", float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_LDS, 4, true),
+        V("16x8x8 t2 reg w3", float, 1024, 3, 16, 8, 8, 1, 2, 128, false, true, true, TW_REG, 3, false),
+        V("16x8x8 t2 lds w4 pf", float, 1024, 3, 16, 8, 8, 1, 2, 128, false, true, true, TW_LDS, 4, true),
+        V("8x16x8 t4 reg w3", float, 1024, 3, 8, 16, 8, 1, 4, 256, false, true, true, TW_REG, 3, false),
+        V("8x8x16 t4 reg w3", float, 1024, 3, 8, 8, 16, 1, 4, 256, false, true, true, TW_REG, 3, false),
+        V("4x4x8x8 t2 reg w4", float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_REG, 4, false),
+        V("4x4x8x8 t2 reg w5", float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_REG, 5, false),
+        V("4x4x8x8 t2 reg w4 pf", float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_REG, 4, true),
+        V("32x32 t8 lds w2", float, 1024, 2, 32, 32, 1, 1, 8, 256, false, true, true, TW_LDS, 2, false),
+        V("32x32 t8 lds w3", float, 1024, 2, 32, 32, 1, 1, 8, 256, false, true, true, TW_LDS, 3, false),
+    };
+#elif GROUP == 2  // ---- config 3: 500k x 93 ----
+    const long long batch = 500000, outer = 1, inner = 1;
+    const int N = 93;
+    std::vector<Variant> vs = {
+        V("31x3 t64 192 glb w1", float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_GLOBAL, 1, false),
+        V("31x3 t64 192 glb w2", float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_GLOBAL, 2, false),
+        V("31x3 t64 192 lds w2", float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 2, false),
+        V("31x3 t64 192 lds w3", float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        V("31x3 t32 96 lds w2", float, 93, 2, 31, 3, 1, 1, 32, 96, false, false, false, TW_LDS, 2, false),
+        V("31x3 t128 384 lds w2", float, 93, 2, 31, 3, 1, 1, 128, 384, false, false, false, TW_LDS, 2, false),
+        V("31x3 t64 64 lds w2", float, 93, 2, 31, 3, 1, 1, 64, 64, false, false, false, TW_LDS, 2, false),
+        V("31x3 t64 128 lds w2", float, 93, 2, 31, 3, 1, 1, 64, 128, false, false, false, TW_LDS, 2, false),
+        V("31x3 t64 256 lds w2", float, 93, 2, 31, 3, 1, 1, 64, 256, false, false, false, TW_LDS, 2, false),
+        V("3x31 t64 192 lds w2", float, 93, 2, 3, 31, 1, 1, 64, 192, false, false, false, TW_LDS, 2, false),
+    };
+#elif GROUP == 3  // ---- 500k x 128 rows (config 1 shape, config 5 z axis) ----
+    const long long batch = 500000, outer = 1, inner = 1;
+    const int N = 128;
+    std::vector<Variant> vs = {
+        V("8x4x4 t16 reg w1", float, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
+        V("8x4x4 t16 reg w4 pf", float, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 4, true),
+        V("8x16 t32 reg w2", float, 128, 2, 8, 16, 1, 1, 32, 256, false, true, true, TW_REG, 2, false),
+        V("16x8 t32 reg w2", float, 128, 2, 16, 8, 1, 1, 32, 256, false, true, true, TW_REG, 2, false),
+        V("8x16 t32 reg w2 ldsout", float, 128, 2, 8, 16, 1, 1, 32, 256, false, true, false, TW_REG, 2, false),
+        V("16x8 t32 reg w2 ldsin", float, 128, 2, 16, 8, 1, 1, 32, 256, false, false, true, TW_REG, 2, false),
+    };
+#elif GROUP == 4  // ---- config 4 second pass: columns of 640, inner 480, 100 images ----
+    const long long batch = 100, outer = 1, inner = 480;
+    const int N = 640;
+    std::vector<Variant> vs = {
+        V("c640 10x8x8 t8 256 glb", float, 640, 3, 10, 8, 8, 1, 8, 256, true, true, true, TW_GLOBAL, 1, false),
+        V("c640 10x8x8 t8 256 lds", float, 640, 3, 10, 8, 8, 1, 8, 256, true, true, true, TW_LDS, 1, false),
+        V("c640 10x8x8 t8 256 lds w2", float, 640, 3, 10, 8, 8, 1, 8, 256, true, true, true, TW_LDS, 2, false),
+        V("c640 10x8x8 t16 256 lds", float, 640, 3, 10, 8, 8, 1, 16, 256, true, true, true, TW_LDS, 1, false),
+        V("c640 10x8x8 t16 512 lds", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 10x8x8 t4 128 lds w2", float, 640, 3, 10, 8, 8, 1, 4, 128, true, true, true, TW_LDS, 2, false),
+        V("c640 8x8x10 t8 256 lds w2", float, 640, 3, 8, 8, 10, 1, 8, 256, true, true, true, TW_LDS, 2, false),
+        V("c640 16x8x5 t8 256 lds w2", float, 640, 3, 16, 8, 5, 1, 8, 256, true, true, true, TW_LDS, 2, false),
+        V("c640 20x32 t8 256 lds w2", float, 640, 2, 20, 32, 1, 1, 8, 256, true, true, true, TW_LDS, 2, false),
+    };
+#elif GROUP == 5  // ---- config 4 first pass: 64000 rows of 480 ----
+    const long long batch = 64000, outer = 1, inner = 1;
+    const int N = 480;
+    std::vector<Variant> vs = {
+        V("r480 10x6x8 t8 128 glb", float, 480, 3, 10, 6, 8, 1, 8, 128, false, true, true, TW_GLOBAL, 1, false),
+        V("r480 10x6x8 t8 128 lds w2", float, 480, 3, 10, 6, 8, 1, 8, 128, false, true, true, TW_LDS, 2, false),
+        V("r480 10x6x8 t8 256 lds w2", float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, false),
+        V("r480 10x6x8 t16 256 lds w2", float, 480, 3, 10, 6, 8, 1, 16, 256, false, true, true, TW_LDS, 2, false),
+        V("r480 10x6x8 t4 128 lds w3", float, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 3, false),
+        V("r480 8x6x10 t8 256 lds w2", float, 480, 3, 8, 6, 10, 1, 8, 256, false, true, true, TW_LDS, 2, false),
+        V("r480 16x30 t8 256 lds w2", float, 480, 2, 16, 30, 1, 1, 8, 256, false, true, true, TW_LDS, 2, false),
+        V("r480 4x4x30 t8 256 lds w2", float, 480, 3, 4, 4, 30, 1, 8, 256, false, true, true, TW_LDS, 2, false),
+        V("r480 10x6x8 t8 256 lds w2 pf", float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    };
+#elif GROUP == 6  // ---- config 5 y / x axes: columns of 128 ----
+    const long long batch = 10, outer = 128, inner = 128;  // y axis; x axis is outer 1, inner 16384
+    const int N = 128;
+    std::vector<Variant> vs = {
+        V("c128 16x8 t16 128 reg", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_REG, 1, false),
+        V("c128 16x8 t16 128 reg w3", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_REG, 3, false),
+        V("c128 16x8 t16 128 lds w4", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_LDS, 4, false),
+        V("c128 8x16 t16 128 lds w4", float, 128, 2, 8, 16, 1, 1, 16, 128, true, true, true, TW_LDS, 4, false),
+        V("c128 8x4x4 t16 256 lds w4", float, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
+        V("c128 16x8 t32 256 lds w4", float, 128, 2, 16, 8, 1, 1, 32, 256, true, true, true, TW_LDS, 4, false),
+        V("c128 16x8 t8 64 lds w4", float, 128, 2, 16, 8, 1, 1, 8, 64, true, true, true, TW_LDS, 4, false),
+        V("c128 16x8 t16 128 lds w4 pf", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_LDS, 4, true),
+    };
+#else
+#error "define GROUP"
+#endif
+
+    const size_t elems = (size_t)batch * outer * inner * N;
+    const size_t bytes = elems * 8;
+    std::vector<float> h(elems * 2);
+    unsigned s = 12345;
+    for (auto& x : h) {
+        s = s * 1664525u + 1013904223u;
+        x = ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f;
+    }
+    std::vector<float> tw(2 * N);
+    for (int n = 0; n < N; ++n) {
+        tw[2 * n] = (float)cos(-2.0 * M_PI * n / N);
+        tw[2 * n + 1] = (float)sin(-2.0 * M_PI * n / N);
+    }
+    void *din, *dout, *dref, *dtw;
+    CK(hipMalloc(&din, bytes));
+    CK(hipMalloc(&dout, bytes));
+    CK(hipMalloc(&dref, bytes));
+    CK(hipMalloc(&dtw, tw.size() * 4));
+    CK(hipMemcpy(din, h.data(), bytes, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+
+    const bool inplace = inner != 1;  // column kernels run in place on `out`
+    auto prep = [&](void* dst) {
+        if (inplace) CK(hipMemcpyAsync(dst, din, bytes, hipMemcpyDeviceToDevice, 0));
+    };
+
+    // correctness vs the first variant (sampled)
+    const size_t sample = std::min<size_t>(elems * 2, 1u << 22);
+    std::vector<float> ref(sample), got(sample);
+    prep(dref);
+    vs[0].run(inplace ? dref : din, dref, dtw, batch, outer, inner);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(ref.data(), dref, sample * 4, hipMemcpyDeviceToHost));
+    // tail sample too
+    std::vector<float> ref_tail(sample), got_tail(sample);
+    CK(hipMemcpy(ref_tail.data(), (char*)dref + bytes - sample * 4, sample * 4, hipMemcpyDeviceToHost));
+    double refnorm = 0;
+    for (float x : ref) refnorm += (double)x * x;
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<double> best(vs.size(), 1e30), sum(vs.size(), 0);
+    std::vector<double> err(vs.size(), 0);
+    for (size_t i = 0; i < vs.size(); ++i) {
+        CK(hipMemsetAsync(dout, 0xFF, bytes, 0));
+        prep(dout);
+        vs[i].run(inplace ? dout : din, dout, dtw, batch, outer, inner);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), dout, sample * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(got_tail.data(), (char*)dout + bytes - sample * 4, sample * 4, hipMemcpyDeviceToHost));
+        double d = 0;
+        for (size_t k = 0; k < sample; ++k) {
+            double a = (double)got[k] - ref[k], b = (double)got_tail[k] - ref_tail[k];
+            d += a * a + b * b;
+        }
+        err[i] = sqrt(d / (2 * refnorm));
+    }
+    const int rounds = 5, inner_iters = inplace ? 1 : 10;
+    for (int r = 0; r < rounds; ++r) {
+        for (size_t i = 0; i < vs.size(); ++i) {
+            if (inplace) {
+                // in-place kernels: time single launches on fresh data (data stays finite either way)
+                float tot = 0;
+                for (int it = 0; it < 5; ++it) {
+                    prep(dout);
+                    CK(hipEventRecord(e0, 0));
+                    vs[i].run(dout, dout, dtw, batch, outer, inner);
+                    CK(hipEventRecord(e1, 0));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    tot += ms;
+                }
+                double ms = tot / 5;
+                best[i] = std::min(best[i], ms);
+                sum[i] += ms;
+            } else {
+                vs[i].run(din, dout, dtw, batch, outer, inner);  // warm
+                CK(hipEventRecord(e0, 0));
+                for (int it = 0; it < inner_iters; ++it) vs[i].run(din, dout, dtw, batch, outer, inner);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                ms /= inner_iters;
+                best[i] = std::min(best[i], (double)ms);
+                sum[i] += ms;
+            }
+        }
+    }
+    printf("GROUP %d  N=%d  tensor %.1f MB  (wg/cu override %d)\n", GROUP, N, bytes / 1e6, g_wg_override);
+    printf("%-28s %9s %9s %8s %8s %10s\n", "variant", "min ms", "mean ms", "GB/s", "frac8T", "relerr");
+    for (size_t i = 0; i < vs.size(); ++i) {
+        double gbs = 2.0 * bytes / best[i] / 1e6;
+        printf("%-28s %9.4f %9.4f %8.0f %8.3f %10.2e  lds %zu\n", vs[i].name.c_str(), best[i], sum[i] / rounds, gbs,
+               gbs / 8000.0, err[i], vs[i].lds);
+    }
+    return 0;
+}
