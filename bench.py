@@ -49,12 +49,46 @@ def flops_5nlogn(shape):
     return 5.0 * n * math.log2(n) * shape[0]
 
 
+def host_cpu_share(nproc):
+    """Cores this process may really use: min(affinity, cgroup cpu.max quota, nproc)."""
+    n = nproc
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def measured_traffic(workload, kernels):
+    """HBM bytes per launch from the committed PMC passes (profiles/rNN_<workload>.json, written by
+    tools/summarize_prof.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of THIS command,
+    FETCH_SIZE corrected by the calibrated gfx950 factor).  None when no profile of the current kernel
+    set is committed -- counters cannot be collected from inside an un-profiled run."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        ks = [k for k in d.get("kernels", []) if "hbm_traffic_bytes" in k]
+        if ks and len(ks) == len(set(kernels)):
+            best = (sum(k["hbm_traffic_bytes"] for k in ks), os.path.basename(f))
+    return best
+
+
 def cpu_baseline(shape, bases, budget_s=12.0):
     """Oracle timed on a bounded sample (leading-batch subset) of the workload."""
     import numpy as np
     from oracle import mifft_oracle as O
 
-    cores = O.num_procs()
+    cores = host_cpu_share(O.num_procs())
     rng = np.random.default_rng(1234)
     per = int(np.prod(shape[1:]))
 
@@ -148,6 +182,7 @@ def main():
         algo_bytes = 16.0 * elems  # per launch sequence on ONE gpu
         achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
         kernels = [plan.kernel_name(d) for d in range(len(shape) - 1)]
+        traffic = measured_traffic(args.workload, kernels)
         result = {
             "metric": "C2C GFLOP/s (5Nlog2N) + ms/transform, 100k×1024 fp32 @1/2/4/8 MI355X",
             "value": round(value, 2),
@@ -179,7 +214,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic[0] if traffic else None,
+                "traffic_source": traffic[1] if traffic else None,
                 "kernel": "+".join(kernels),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "launch_ms_hip_events": round(launch_ms, 5),
