@@ -147,8 +147,16 @@ def main():
     x = torch.randn(tuple(shape) + (2,), generator=gen, device=dev, dtype=torch.float32)
     out = torch.empty_like(x)
     ctx = mf.DeviceContext(local_rank)
-    plan = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, bases=bases, ctx=ctx,
-                       faithful_stages=args.faithful)
+    if distributed:
+        # weak scaling: the global problem is world x (per-GPU shape); every rank owns one resident slab
+        from hackathon_fft_amd.dist import ShardedFFT
+        gshape = (shape[0] * world,) + tuple(shape[1:]) + (2,)
+        sharded = ShardedFFT(torch.float32, torch.float32, gshape, gshape, bases=bases, device=local_rank)
+        assert sharded.slab_in_shape == tuple(x.shape)
+        plan, ctx = sharded._backend.plan, sharded._backend.ctx
+    else:
+        plan = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, bases=bases, ctx=ctx,
+                           faithful_stages=args.faithful)
 
     def barrier():
         torch.cuda.synchronize()
