@@ -74,12 +74,75 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     // ---- strided dimensions, fp32 (in place, LDS column tiles) ----
-    MIFFT_CFG("cols640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
-    MIFFT_CFG("cols480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("cols640_4x4x8x5", float, MIFFT_F32, 640, 4, 4, 4, 8, 5, 16, 512, true, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("cols480_4x4x6x5", float, MIFFT_F32, 480, 4, 4, 4, 6, 5, 16, 512, true, true, true, TW_LDS, 1, false),
     MIFFT_CFG("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, true, TW_LDS, 2, false),
 };
+
+template <class CR, class CC>
+static int launch_plane(const Plan& plan, const DimPass& pass, const void* in, void* out, int64_t count,
+                        hipStream_t stream) {
+    if (count == 0) return MIFFT_OK;
+    TileParams tp{};
+    tp.in = in;
+    tp.out = out;
+    tp.tw = pass.d_twiddle;
+    tp.inverse = plan.inverse;
+    tp.scale = plan.inverse ? 1.0 / ((double)pass.N * (double)pass.N1) : 1.0;
+    tp.inner = CC::TILE;  // column stride inside a plane = N2
+    tp.tiles_per_outer = 1;
+    tp.n_rows = 0;
+    tp.n_tiles = count * pass.outer;  // planes
+    auto k = plane_kernel<CR, CC>;
+    static bool attr_set = false;
+    if (CR::LDS_BYTES > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR::LDS_BYTES);
+        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute");
+        attr_set = true;
+    }
+    const long long grid = tile_grid<CR>(plan.num_cus, tp.n_tiles);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(CR::THREADS), CR::LDS_BYTES, stream, tp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_error(e, "plane_kernel launch");
+    return MIFFT_OK;
+}
+
+struct PlaneEntry {
+    int out_dtype;
+    int N1, N2;
+    const char* name;
+    LaunchFn launch;
+    int threads;
+    size_t lds;
+};
+
+// rows configuration (N2, TILE = N1, HBM -> LDS) then columns configuration (N1, TILE = N2, LDS -> HBM)
+// (a 128 x 128 plane = 128 KiB fits LDS but leaves ONE workgroup per CU, which cannot overlap its HBM
+//  and LDS phases: measured 0.121 ms for z+y of 10 x 128^3 against 0.060 + 0.061 ms for the two
+//  separate passes -- tools/tune/tune_tile.hip GROUP 7 -- so 128^3 keeps three passes.)
+using Plane64R = TileCfg<float, 64, 3, 4, 4, 4, 1, 64, 512, false, true, false, TW_LDS, 2, true>;
+using Plane64C = TileCfg<float, 64, 3, 4, 4, 4, 1, 64, 512, true, false, true, TW_LDS, 2, false>;
+
+static const PlaneEntry kPlaneTable[] = {
+    {MIFFT_F32, 64, 64, "plane64x64_4x4x4", launch_plane<Plane64R, Plane64C>, 512, Plane64R::LDS_BYTES},
+};
+
+bool select_fast_plane(const Plan& plan, DimPass& pass) {
+    if (plan.in_components != 2 || plan.in_dtype != plan.out_dtype) return false;
+    for (const PlaneEntry& e : kPlaneTable) {
+        if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
+        pass.kernel_name = e.name;
+        pass.launch = e.launch;
+        pass.tile = 1;
+        pass.threads = e.threads;
+        pass.lds_bytes = e.lds;
+        pass.ld = (int)pass.N;
+        return true;
+    }
+    return false;
+}
 
 bool select_fast(const Plan& plan, DimPass& pass) {
     // fast families take complex input of the output dtype; everything else (real / integer

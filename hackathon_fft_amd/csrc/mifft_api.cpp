@@ -199,6 +199,24 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) p.num_cus = prop.multiProcessorCount;
 
     // ---- passes in execution order: last dimension first ----
+    p.stage_radices = ordered;
+    auto upload_twiddles = [&](DimPass& ps) -> hipError_t {
+        hipError_t err;
+        if (out_dtype == MIFFT_F32) {
+            std::vector<float> tab;
+            fill_twiddles(tab, ps.N, inverse != 0);
+            err = hipMalloc(&ps.d_twiddle, tab.size() * sizeof(float));
+            if (err == hipSuccess)
+                err = hipMemcpy(ps.d_twiddle, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+        } else {
+            std::vector<double> tab;
+            fill_twiddles(tab, ps.N, inverse != 0);
+            err = hipMalloc(&ps.d_twiddle, tab.size() * sizeof(double));
+            if (err == hipSuccess)
+                err = hipMemcpy(ps.d_twiddle, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+        }
+        return err;
+    };
     for (int i = ndim - 1; i >= 0; --i) {
         DimPass ps;
         ps.dim_index = i;
@@ -211,7 +229,21 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
         ps.processed = processed[i];
         ps.first = i == ndim - 1;
         bool ok = false;
-        if (!(flags & MIFFT_FLAG_FAITHFUL_STAGES)) ok = select_fast(p, ps);
+        if (!(flags & MIFFT_FLAG_FAITHFUL_STAGES)) {
+            if (i == ndim - 1 && ndim >= 2) {  // try to fuse the two innermost dimensions in one LDS plane
+                DimPass pl = ps;
+                pl.dim_index2 = i - 1;
+                pl.N1 = dims[i - 1];
+                pl.outer = 1;
+                for (int k = 0; k < i - 1; ++k) pl.outer *= dims[k];
+                if (select_fast_plane(p, pl)) {
+                    ps = pl;
+                    ok = true;
+                    --i;  // dimension i-1 is covered by this pass
+                }
+            }
+            if (!ok) ok = select_fast(p, ps);
+        }
         if (!ok) {
             std::string why;
             ok = select_generic(p, ps, why);
@@ -221,18 +253,7 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                 return set_error(MIFFT_ERR_TOO_LARGE, why);
             }
         }
-        // twiddle table of the dimension
-        if (out_dtype == MIFFT_F32) {
-            std::vector<float> tab;
-            fill_twiddles(tab, ps.N, inverse != 0);
-            e = hipMalloc(&ps.d_twiddle, tab.size() * sizeof(float));
-            if (e == hipSuccess) e = hipMemcpy(ps.d_twiddle, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
-        } else {
-            std::vector<double> tab;
-            fill_twiddles(tab, ps.N, inverse != 0);
-            e = hipMalloc(&ps.d_twiddle, tab.size() * sizeof(double));
-            if (e == hipSuccess) e = hipMemcpy(ps.d_twiddle, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
-        }
+        e = upload_twiddles(ps);
         p.passes.push_back(ps);
         if (e != hipSuccess) {
             free_plan_device(p);
@@ -281,18 +302,16 @@ void mifft_plan_destroy(mifft_plan* plan) {
 
 int mifft_plan_stages(const mifft_plan* plan, int dim, uint32_t* radices_out, int capacity) {
     if (!plan) return set_error(MIFFT_ERR_NULL, "plan is NULL");
-    for (const DimPass& ps : plan->p.passes)
-        if (ps.dim_index == dim) {
-            for (size_t i = 0; i < ps.radices.size() && (int)i < capacity; ++i) radices_out[i] = ps.radices[i];
-            return (int)ps.radices.size();
-        }
-    return set_error(MIFFT_ERR_BAD_RANK, "dim out of range");
+    if (dim < 0 || dim >= plan->p.ndim) return set_error(MIFFT_ERR_BAD_RANK, "dim out of range");
+    const std::vector<uint32_t>& r = plan->p.stage_radices[dim];
+    for (size_t i = 0; i < r.size() && (int)i < capacity; ++i) radices_out[i] = r[i];
+    return (int)r.size();
 }
 
 const char* mifft_plan_kernel_name(const mifft_plan* plan, int dim) {
     if (!plan) return "";
     for (const DimPass& ps : plan->p.passes)
-        if (ps.dim_index == dim) return ps.kernel_name;
+        if (ps.dim_index == dim || ps.dim_index2 == dim) return ps.kernel_name;
     return "";
 }
 

@@ -42,6 +42,8 @@ typedef int (*LaunchFn)(const Plan& plan, const DimPass& pass, const void* in, v
 
 struct DimPass {
     int dim_index = 0;
+    int dim_index2 = -1;  // >= 0: a fused plane pass that also transforms this (next-outer) dimension
+    int64_t N1 = 0;       // length of dim_index2
     int64_t N = 0;        // transform length
     int64_t inner = 1;    // element stride of this dim = prod(dims after it)
     int64_t outer = 1;    // prod(dims before it)   (times batch at launch)
@@ -71,6 +73,7 @@ struct Plan {
     uint32_t flags = 0;
     int num_cus = 256;
     std::vector<DimPass> passes;  // in execution order: last dim first
+    std::vector<std::vector<uint32_t>> stage_radices;  // per dim: the user's ordered stages (introspection)
     size_t in_elem_bytes() const;
     size_t out_elem_bytes() const;  // bytes of one complex output element
 };
@@ -79,6 +82,8 @@ struct Plan {
 // accepts the (plan, pass) pair.
 bool select_generic(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_fast(const Plan& plan, DimPass& pass);
+// fused pass over the two innermost dimensions (pass.N = contiguous dim, pass.N1 = the next one)
+bool select_fast_plane(const Plan& plan, DimPass& pass);
 
 inline size_t dtype_size(int dt) {
     switch (dt) {

@@ -380,6 +380,57 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// plane_kernel<CR, CC>: the two innermost dimensions (N1 x N2, N2 contiguous) of one 2-D slice are
+// transformed inside ONE LDS tile: the rows (length N2) by the ROWS configuration CR -- pass 0 straight
+// from HBM, last pass left in LDS in natural order -- then the columns (length N1, LDS stride N2) by
+// the COLS configuration CC, whose last pass stores straight to HBM along the contiguous axis.
+// One HBM read + one HBM write for two dimensions; the reference spends a row kernel, a transpose
+// kernel, a row kernel and a transpose back (fft/fft/_ndim_fft_gpu.mojo:634-642).
+// Requirements: CR::N == CC::TILE (= N2), CR::TILE == CC::N (= N1), CR::LD == N2, equal thread counts,
+// identical LDS twiddle tables (N1 == N2 with the same radices).
+// ---------------------------------------------------------------------------------------------
+template <class CR, class CC>
+__global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const TileParams p) {
+    using T = typename CR::T;
+    using V = cpx<T>;
+    static_assert(!CR::COLS && CC::COLS, "rows configuration first, columns configuration second");
+    static_assert(CR::N == CC::TILE && CR::TILE == CC::N && CR::LD == CR::N, "plane geometry");
+    static_assert(CR::THREADS == CC::THREADS, "one thread count");
+    static_assert(CR::FIRST_DIRECT && !CR::LAST_DIRECT && !CC::FIRST_DIRECT && CC::LAST_DIRECT, "plane data flow");
+    static_assert(CR::TWMODE == TW_LDS && CC::TWMODE == TW_LDS && CR::N == CC::N && CR::TWL_TOTAL == CC::TWL_TOTAL,
+                  "square planes with one shared LDS twiddle table");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V* lds = (V*)smem;
+    const int tid = threadIdx.x;
+    V twr[1];
+    fill_lds_tw<CR, 1>(lds + CR::DATA_ELEMS, (const V*)p.tw, tid, p.inverse);
+    __syncthreads();
+
+    constexpr long long PLANE = (long long)CR::N * CR::TILE;
+    V pre[CR::PREFETCH ? CR::IPT(0) : 1][CR::R(0)];
+    long long t = blockIdx.x;
+    if constexpr (CR::PREFETCH) {
+        if (t < p.n_tiles) load_pass0<CR>(p, pre, t * PLANE, CR::TILE, tid);
+    }
+    for (; t < p.n_tiles; t += gridDim.x) {
+        const long long base = t * PLANE;
+        V cur[CR::PREFETCH ? CR::IPT(0) : 1][CR::R(0)];
+        if constexpr (CR::PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < CR::IPT(0); ++k)
+#pragma unroll
+                for (int j = 0; j < CR::R(0); ++j) cur[k][j] = pre[k][j];
+            const long long tn = t + gridDim.x;
+            if (tn < p.n_tiles) load_pass0<CR>(p, pre, tn * PLANE, CR::TILE, tid);
+        }
+        run_pass<CR, 0>(p, lds, twr, cur, base, CR::TILE, tid);  // rows: HBM -> ... -> LDS (natural order)
+        V none[1][CC::R(0)];
+        run_pass<CC, 0>(p, lds, twr, none, base, CC::TILE, tid);  // columns: LDS -> ... -> HBM
+    }
+}
+
 // persistent grid: enough workgroups to fill every CU to its LDS / wave limit
 template <class C>
 inline long long tile_grid(int num_cus, long long n_tiles, int wg_per_cu_override = 0) {

@@ -90,7 +90,13 @@ BASELINE_CASES = [
     ((301, 93), [[31, 3]]),
     ((2, 640, 480), None),
     ((2, 128, 128, 128), None),
-    ((3, 64, 64, 64), None),
+    ((3, 64, 64, 64), None),     # fused 64x64 LDS plane + in-place column tiles
+    ((70, 64, 64), None),        # 2-D through the fused plane kernel alone
+    ((2, 256, 256), None),
+    ((3, 512), None),
+    ((3, 2048), None),
+    ((5, 256), None),
+    ((9, 64), None),
     ((5, 16, 12, 10), None),
     ((130, 480), None),
     ((90, 640), None),

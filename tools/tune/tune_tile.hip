@@ -68,7 +68,37 @@ Variant make(const char* name) {
     return v;
 }
 
+template <class CR, class CC>
+Variant make_plane(const char* name) {
+    Variant v;
+    v.name = name;
+    v.lds = CR::LDS_BYTES;
+    v.run = [](const void* in, void* out, const void* tw, long long batch, long long outer, long long inner) {
+        TileParams tp{};
+        tp.in = in;
+        tp.out = out;
+        tp.tw = tw;
+        tp.inverse = 0;
+        tp.scale = 1.0;
+        tp.inner = CC::TILE;
+        tp.tiles_per_outer = 1;
+        tp.n_tiles = batch * outer;  // planes
+        auto k = plane_kernel<CR, CC>;
+        static bool set = false;
+        if (!set && CR::LDS_BYTES > 64 * 1024) {
+            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR::LDS_BYTES));
+            set = true;
+        }
+        long long grid = tile_grid<CR>(g_cus, tp.n_tiles, g_wg_override);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(CR::THREADS), CR::LDS_BYTES, 0, tp);
+    };
+    return v;
+}
+
 #define V(NAME, ...) make<TileCfg<__VA_ARGS__>>(NAME)
+#define PL(NAME, THR, MINW, PF, R0, R1, R2, R3, NP)                                                              \
+    make_plane<TileCfg<float, 128, NP, R0, R1, R2, R3, 128, THR, false, true, false, TW_LDS, MINW, PF>,          \
+               TileCfg<float, 128, NP, R0, R1, R2, R3, 128, THR, true, false, true, TW_LDS, MINW, false>>(NAME)
 
 int main(int argc, char** argv) {
     if (argc > 1) g_wg_override = atoi(argv[1]);
@@ -137,15 +167,19 @@ int main(int argc, char** argv) {
     const long long batch = 100, outer = 1, inner = 480;
     const int N = 640;
     std::vector<Variant> vs = {
-        V("c640 10x8x8 t8 256 glb", float, 640, 3, 10, 8, 8, 1, 8, 256, true, true, true, TW_GLOBAL, 1, false),
-        V("c640 10x8x8 t8 256 lds", float, 640, 3, 10, 8, 8, 1, 8, 256, true, true, true, TW_LDS, 1, false),
-        V("c640 10x8x8 t8 256 lds w2", float, 640, 3, 10, 8, 8, 1, 8, 256, true, true, true, TW_LDS, 2, false),
-        V("c640 10x8x8 t16 256 lds", float, 640, 3, 10, 8, 8, 1, 16, 256, true, true, true, TW_LDS, 1, false),
-        V("c640 10x8x8 t16 512 lds", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
-        V("c640 10x8x8 t4 128 lds w2", float, 640, 3, 10, 8, 8, 1, 4, 128, true, true, true, TW_LDS, 2, false),
-        V("c640 8x8x10 t8 256 lds w2", float, 640, 3, 8, 8, 10, 1, 8, 256, true, true, true, TW_LDS, 2, false),
-        V("c640 16x8x5 t8 256 lds w2", float, 640, 3, 16, 8, 5, 1, 8, 256, true, true, true, TW_LDS, 2, false),
-        V("c640 20x32 t8 256 lds w2", float, 640, 2, 20, 32, 1, 1, 8, 256, true, true, true, TW_LDS, 2, false),
+        V("c640 4x4x5x8 t16 512 lds", float, 640, 4, 4, 4, 5, 8, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 4x4x5x8 t16 512 glb w4", float, 640, 4, 4, 4, 5, 8, 16, 512, true, true, true, TW_GLOBAL, 4, false),
+        V("c640 4x4x5x8 t16 512 glb w2", float, 640, 4, 4, 4, 5, 8, 16, 512, true, true, true, TW_GLOBAL, 2, false),
+        V("c640 4x4x5x8 t16 256 glb w2", float, 640, 4, 4, 4, 5, 8, 16, 256, true, true, true, TW_GLOBAL, 2, false),
+        V("c640 4x4x5x8 t16 512 reg w4", float, 640, 4, 4, 4, 5, 8, 16, 512, true, true, true, TW_REG, 4, false),
+        V("c640 4x4x5x8 t16 1024 lds", float, 640, 4, 4, 4, 5, 8, 16, 1024, true, true, true, TW_LDS, 1, false),
+        V("c640 5x4x4x8 t16 512 lds", float, 640, 4, 5, 4, 4, 8, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 8x5x4x4 t16 512 lds", float, 640, 4, 8, 5, 4, 4, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 4x5x4x8 t16 512 lds", float, 640, 4, 4, 5, 4, 8, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 4x4x4x10 t16 512 lds", float, 640, 4, 4, 4, 4, 10, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 4x4x8x5 t16 512 lds", float, 640, 4, 4, 4, 8, 5, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 4x4x5x8 t8 256 lds w2", float, 640, 4, 4, 4, 5, 8, 8, 256, true, true, true, TW_LDS, 2, false),
+        V("c640 4x4x5x8 t12 384 lds", float, 640, 4, 4, 4, 5, 8, 12, 384, true, true, true, TW_LDS, 2, false),
     };
 #elif GROUP == 5  // ---- config 4 first pass: 64000 rows of 480 ----
     const long long batch = 64000, outer = 1, inner = 1;
@@ -174,11 +208,31 @@ int main(int argc, char** argv) {
         V("c128 16x8 t8 64 lds w4", float, 128, 2, 16, 8, 1, 1, 8, 64, true, true, true, TW_LDS, 4, false),
         V("c128 16x8 t16 128 lds w4 pf", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_LDS, 4, true),
     };
+#elif GROUP == 7  // ---- config 5 fused z+y plane pass: 1280 planes of 128x128 ----
+    const long long batch = 10, outer = 128, inner = 1;
+    const int N = 128;  // tensor = batch*outer planes of 128x128 -> elems = batch*outer*128*128
+    std::vector<Variant> vs = {
+        PL("plane 8x4x4 1024 w4", 1024, 4, false, 8, 4, 4, 1, 3),
+        PL("plane 8x4x4 1024 w4 pf", 1024, 4, true, 8, 4, 4, 1, 3),
+        PL("plane 8x4x4 512 w2", 512, 2, false, 8, 4, 4, 1, 3),
+        PL("plane 8x4x4 512 w2 pf", 512, 2, true, 8, 4, 4, 1, 3),
+        PL("plane 16x8 512 w2", 512, 2, false, 16, 8, 1, 1, 2),
+        PL("plane 16x8 512 w2 pf", 512, 2, true, 16, 8, 1, 1, 2),
+        PL("plane 16x8 1024 w4", 1024, 4, false, 16, 8, 1, 1, 2),
+        PL("plane 8x16 512 w2 pf", 512, 2, true, 8, 16, 1, 1, 2),
+        PL("plane 4x4x8 1024 w4", 1024, 4, false, 4, 4, 8, 1, 3),
+        PL("plane 4x4x8 512 w2 pf", 512, 2, true, 4, 4, 8, 1, 3),
+        PL("plane 8x4x4 256 w1 pf", 256, 1, true, 8, 4, 4, 1, 3),
+    };
 #else
 #error "define GROUP"
 #endif
 
+#if GROUP == 7
+    const size_t elems = (size_t)batch * outer * 128 * 128;
+#else
     const size_t elems = (size_t)batch * outer * inner * N;
+#endif
     const size_t bytes = elems * 8;
     std::vector<float> h(elems * 2);
     unsigned s = 12345;
