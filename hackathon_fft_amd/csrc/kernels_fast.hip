@@ -14,6 +14,7 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
     tp.out = out;
     tp.tw = pass.d_twiddle;
     tp.inverse = plan.inverse;
+    tp.in_real = (pass.first && plan.in_components == 1) ? 1 : 0;
     tp.scale = plan.inverse ? 1.0 / (double)pass.N : 1.0;
     if (C::COLS) {
         tp.inner = pass.inner;
@@ -79,6 +80,21 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, true, TW_LDS, 2, false),
+    // ---- fp64 (the reference's own tests run in float64, fft/tests.mojo:394-417): same template, 16-byte
+    //      elements; smaller butterflies per pass keep the live registers under 128 ----
+    MIFFT_CFG("rows1024_f64_4x4x8x8", double, MIFFT_F64, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("rows512_f64_8x8x8", double, MIFFT_F64, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("rows256_f64_4x8x8", double, MIFFT_F64, 256, 3, 4, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("rows128_f64_8x4x4", double, MIFFT_F64, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("rows64_f64_4x4x4", double, MIFFT_F64, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("rows93_f64_31x3", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 32, 96, false, false, false, TW_LDS, 1, false),
+    MIFFT_CFG("rows480_f64_10x6x8", double, MIFFT_F64, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("rows640_f64_10x8x8", double, MIFFT_F64, 640, 3, 10, 8, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("cols640_f64_4x4x8x5", double, MIFFT_F64, 640, 4, 4, 4, 8, 5, 8, 256, true, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("cols480_f64_4x4x6x5", double, MIFFT_F64, 480, 4, 4, 4, 6, 5, 8, 256, true, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("cols128_f64_8x4x4", double, MIFFT_F64, 128, 3, 8, 4, 4, 1, 8, 128, true, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("cols64_f64_4x4x4", double, MIFFT_F64, 64, 3, 4, 4, 4, 1, 8, 128, true, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("cols256_f64_4x8x8", double, MIFFT_F64, 256, 3, 4, 8, 8, 1, 8, 256, true, true, true, TW_LDS, 1, false),
 };
 
 template <class CR, class CC>
@@ -90,6 +106,7 @@ static int launch_plane(const Plan& plan, const DimPass& pass, const void* in, v
     tp.out = out;
     tp.tw = pass.d_twiddle;
     tp.inverse = plan.inverse;
+    tp.in_real = plan.in_components == 1 ? 1 : 0;
     tp.scale = plan.inverse ? 1.0 / ((double)pass.N * (double)pass.N1) : 1.0;
     tp.inner = CC::TILE;  // column stride inside a plane = N2
     tp.tiles_per_outer = 1;
@@ -130,7 +147,7 @@ static const PlaneEntry kPlaneTable[] = {
 };
 
 bool select_fast_plane(const Plan& plan, DimPass& pass) {
-    if (plan.in_components != 2 || plan.in_dtype != plan.out_dtype) return false;
+    if (plan.in_dtype != plan.out_dtype) return false;
     for (const PlaneEntry& e : kPlaneTable) {
         if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
         pass.kernel_name = e.name;
@@ -145,9 +162,9 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
 }
 
 bool select_fast(const Plan& plan, DimPass& pass) {
-    // fast families take complex input of the output dtype; everything else (real / integer
-    // input, mixed precision) runs on the generic family
-    if (pass.first && (plan.in_components != 2 || plan.in_dtype != plan.out_dtype)) return false;
+    // fast families read real or complex input of the output dtype; integer input and mixed
+    // precision run on the generic family
+    if (pass.first && plan.in_dtype != plan.out_dtype) return false;
     const bool cols = pass.inner != 1;
     for (const FastEntry& e : kFastTable) {
         if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols) continue;

@@ -44,6 +44,7 @@ struct TileParams {
     long long inner;            // COLS
     long long tiles_per_outer;  // COLS
     int inverse;
+    int in_real;   // pass 0 reads a REAL tensor (C_in = 1) and promotes it (fft/fft/_fft.mojo:254-255)
     double scale;  // 1/N for inverse
 };
 
@@ -96,8 +97,10 @@ struct TileCfg {
 template <class C, int E>
 MIFFT_DEV int swz(int n) {
     if constexpr (!C::COLS && is_pow2_ce(C::N) && E >= 0 && E < C::NP - 1) {
+        // LG = log2(lanes per ds_write group): 16 for 8-byte elements (b64), 8 for 16-byte (b128)
+        constexpr int LG = sizeof(typename C::T) == 4 ? 4 : 3;
         constexpr int a = ilog2_ce(C::P(E)), c = ilog2_ce(C::P(E) * C::R(E));
-        constexpr int c4 = c < 4 ? c : 4, hi = c > 4 ? c : 4, nb = c4 - a;
+        constexpr int c4 = c < LG ? c : LG, hi = c > LG ? c : LG, nb = c4 - a;
         if constexpr (nb > 0 && (1 << hi) < C::N) {
             return n ^ (((n >> hi) & ((1 << nb) - 1)) << a);
         } else {
@@ -204,7 +207,13 @@ MIFFT_DEV void load_pass0(const TileParams& p, cpx<typename C::T> (*v)[C::R(0)],
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 V x = {(T)0, (T)0};
-                if (ok) x = gin[gaddr<C>(p, base, c, b + j * NB)];
+                if (ok) {
+                    const long long g = gaddr<C>(p, base, c, b + j * NB);
+                    if (p.in_real)
+                        x.x = ((const T*)p.in)[g];
+                    else
+                        x = gin[g];
+                }
                 v[k][j] = x;
             }
         }
@@ -355,7 +364,11 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             const int total = nv * C::N;
             for (int f = tid; f < total; f += C::THREADS) {
                 const int c = f / C::N, n = f - c * C::N;
-                V x = gin[base + f];
+                V x = {(T)0, (T)0};
+                if (p.in_real)
+                    x.x = ((const T*)p.in)[base + f];
+                else
+                    x = gin[base + f];
                 if (p.inverse) x.y = -x.y;
                 lds[lds_index<C, -1>(c, n)] = x;
             }

@@ -122,13 +122,31 @@ def test_c2c_fp32_vs_oracle(shape, bases, faithful):
     assert rel_l2(back, x) < REL_L2_TOL_F32
 
 
-@pytest.mark.parametrize("shape", [(9, 1024), (11, 93), (2, 40, 30), (1, 8, 6, 10)])
+@pytest.mark.parametrize("shape", [(9, 1024), (11, 93), (2, 40, 30), (1, 8, 6, 10), (5, 128), (3, 64), (3, 256),
+                                   (3, 512), (1, 640, 480), (1, 128, 128, 128), (2, 64, 64, 64), (1, 256, 256)])
 def test_c2c_fp64_vs_oracle(shape):
     rng = np.random.default_rng(99)
     x = rng.standard_normal(shape + (2,))
+    ref = O.fftn(x)
     for faithful in (True, False):
-        out, _ = gpu_fft(x, faithful=faithful)
-        assert rel_l2(out, O.fftn(x)) < REL_L2_TOL_F64
+        out, plan = gpu_fft(x, faithful=faithful)
+        assert rel_l2(out, ref) < REL_L2_TOL_F64, [plan.kernel_name(d) for d in range(len(shape) - 1)]
+        back, _ = gpu_fft(out, inverse=True, faithful=faithful)
+        assert rel_l2(back, x) < REL_L2_TOL_F64
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(8, 1024), (6, 93), (9, 128), (2, 640, 480), (2, 64, 64, 64), (1, 128, 128, 128)])
+def test_real_input_full_spectrum_on_the_fused_kernels(shape, dtype):
+    """C_in = 1 (fft/fft/_fft.mojo:254-255): the fused kernels promote a real row in their HBM load."""
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal(shape + (1,)).astype(dtype)
+    out, plan = gpu_fft(x, out_dtype=dtype)
+    assert plan.kernel_name(len(shape) - 2) != "generic"
+    tol = REL_L2_TOL_F32 if dtype == np.float32 else REL_L2_TOL_F64
+    assert rel_l2(out, O.fftn(x, out_dtype=dtype)) < tol
+    truth = np.fft.fftn(x[..., 0].astype(np.float64), axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(truth, np.float64)) < tol
 
 
 @pytest.mark.parametrize("in_dtype", [np.float32, np.float64, np.uint8, np.int32])
