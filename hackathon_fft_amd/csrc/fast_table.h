@@ -1,0 +1,74 @@
+// fast_table.h -- launcher + table-entry plumbing shared by the translation units that
+// instantiate tile_kernel<> configurations (kernels_fast.hip and the generated tables).
+#pragma once
+
+#include "mifft_internal.h"
+#include "tile_kernel.h"
+
+namespace mifft {
+
+template <class C>
+static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, void* out, int64_t count,
+                       hipStream_t stream) {
+    if (count == 0) return MIFFT_OK;
+    TileParams tp{};
+    tp.in = in;
+    tp.out = out;
+    tp.tw = pass.d_twiddle;
+    tp.inverse = plan.inverse;
+    tp.scale = plan.inverse ? 1.0 / (double)pass.N : 1.0;
+    if (C::COLS) {
+        tp.inner = pass.inner;
+        tp.tiles_per_outer = (pass.inner + C::TILE - 1) / C::TILE;
+        tp.n_tiles = count * pass.outer * tp.tiles_per_outer;
+    } else {
+        tp.n_rows = count * pass.outer;
+        tp.inner = 1;
+        tp.tiles_per_outer = 1;
+        tp.n_tiles = (tp.n_rows + C::TILE - 1) / C::TILE;
+    }
+    auto k = tile_kernel<C>;
+    static bool attr_set = false;
+    if (C::LDS_BYTES > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute");
+        attr_set = true;
+    }
+    const long long grid = tile_grid<C>(plan.num_cus, tp.n_tiles);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), C::LDS_BYTES, stream, tp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_error(e, "tile_kernel launch");
+    return MIFFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// configuration table.  NP, R0..R3, TILE, THREADS, COLS, FIRST_DIRECT, LAST_DIRECT, TWMODE, MINW, PREFETCH
+// ---------------------------------------------------------------------------------------------
+struct FastEntry {
+    bool in_real;  // the kernel promotes a real (C_in = 1) tensor in its pass-0 load
+    int out_dtype;
+    int N;
+    bool cols;
+    const char* name;
+    LaunchFn launch;
+    int tile, threads;
+    size_t lds;
+};
+
+#define MIFFT_CFG_X(REAL, NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                         \
+    {                                                                                                               \
+        REAL, DT, N, COLS, NAME, launch_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL>>,   \
+            TILE, THREADS, TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL>::LDS_BYTES       \
+    }
+
+
+#define MIFFT_CFG(...) MIFFT_CFG_X(false, __VA_ARGS__)
+// complex-input kernel + its real-input twin (contiguous dimension only)
+#define MIFFT_CFG_CR(NAME, ...) MIFFT_CFG_X(false, NAME, __VA_ARGS__), MIFFT_CFG_X(true, NAME "_r", __VA_ARGS__)
+
+// tables instantiated in kernels_fast_gen_rows.hip / kernels_fast_gen_cols.hip (host-only data:
+// kept TU-local there so that the device pass never sees the host launcher pointers)
+const FastEntry* gen_rows_table(int* count);
+const FastEntry* gen_cols_table(int* count);
+
+}  // namespace mifft

@@ -1,79 +1,26 @@
 // kernels_fast.hip -- configuration table + launchers of the register-butterfly Stockham tile
 // kernels (template: tile_kernel.h) for MI355X (gfx950).
-#include "mifft_internal.h"
-#include "tile_kernel.h"
+#include "fast_table.h"
 
 namespace mifft {
-
-template <class C>
-static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, void* out, int64_t count,
-                       hipStream_t stream) {
-    if (count == 0) return MIFFT_OK;
-    TileParams tp{};
-    tp.in = in;
-    tp.out = out;
-    tp.tw = pass.d_twiddle;
-    tp.inverse = plan.inverse;
-    tp.in_real = (pass.first && plan.in_components == 1) ? 1 : 0;
-    tp.scale = plan.inverse ? 1.0 / (double)pass.N : 1.0;
-    if (C::COLS) {
-        tp.inner = pass.inner;
-        tp.tiles_per_outer = (pass.inner + C::TILE - 1) / C::TILE;
-        tp.n_tiles = count * pass.outer * tp.tiles_per_outer;
-    } else {
-        tp.n_rows = count * pass.outer;
-        tp.inner = 1;
-        tp.tiles_per_outer = 1;
-        tp.n_tiles = (tp.n_rows + C::TILE - 1) / C::TILE;
-    }
-    auto k = tile_kernel<C>;
-    static bool attr_set = false;
-    if (C::LDS_BYTES > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute");
-        attr_set = true;
-    }
-    const long long grid = tile_grid<C>(plan.num_cus, tp.n_tiles);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), C::LDS_BYTES, stream, tp);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_error(e, "tile_kernel launch");
-    return MIFFT_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// configuration table.  NP, R0..R3, TILE, THREADS, COLS, FIRST_DIRECT, LAST_DIRECT, TWMODE, MINW, PREFETCH
-// ---------------------------------------------------------------------------------------------
-struct FastEntry {
-    int out_dtype;
-    int N;
-    bool cols;
-    const char* name;
-    LaunchFn launch;
-    int tile, threads;
-    size_t lds;
-};
-
-#define MIFFT_CFG(NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                         \
-    {                                                                                                               \
-        DT, N, COLS, NAME, launch_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF>>,   \
-            TILE, THREADS, TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF>::LDS_BYTES       \
-    }
 
 static const FastEntry kFastTable[] = {
     // Variants chosen with tools/tune/tune_tile.hip on MI355X (min-of-5 interleaved rounds; numbers in
     // DESIGN.md).  Forcing more waves/SIMD than the butterflies' live registers allow spills and
     // loses 2-3x, so MINW is only raised where the kernel fits.
     // ---- contiguous dimension, fp32 ----
-    MIFFT_CFG("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
-    MIFFT_CFG("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
-    MIFFT_CFG("rows256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, false, true, true, TW_REG, 2, true),
-    MIFFT_CFG("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
-    MIFFT_CFG("rows64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_REG, 1, false),
-    MIFFT_CFG("rows2048_16x16x8", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
-    MIFFT_CFG("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
-    MIFFT_CFG("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-    MIFFT_CFG("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
-    MIFFT_CFG("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_CR("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
+    MIFFT_CFG_CR("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
+    MIFFT_CFG_CR("rows256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, false, true, true, TW_REG, 2, true),
+    MIFFT_CFG_CR("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
+    MIFFT_CFG_CR("rows64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_REG, 1, false),
+    MIFFT_CFG_CR("rows2048_16x16x8", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_CR("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
+    // one 128-KiB row per workgroup; twiddles from the global table (the compact LDS table would need 131 KB more)
+    MIFFT_CFG("rows16384_16x16x8x8", float, MIFFT_F32, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, false),
+    MIFFT_CFG_CR("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+    MIFFT_CFG_CR("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_CR("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     // ---- strided dimensions, fp32 (in place, LDS column tiles) ----
     MIFFT_CFG("cols640_4x4x8x5", float, MIFFT_F32, 640, 4, 4, 4, 8, 5, 16, 512, true, true, true, TW_LDS, 1, false),
     MIFFT_CFG("cols480_4x4x6x5", float, MIFFT_F32, 480, 4, 4, 4, 6, 5, 16, 512, true, true, true, TW_LDS, 1, false),
@@ -82,14 +29,14 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, true, TW_LDS, 2, false),
     // ---- fp64 (the reference's own tests run in float64, fft/tests.mojo:394-417): same template, 16-byte
     //      elements; smaller butterflies per pass keep the live registers under 128 ----
-    MIFFT_CFG("rows1024_f64_4x4x8x8", double, MIFFT_F64, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 1, false),
-    MIFFT_CFG("rows512_f64_8x8x8", double, MIFFT_F64, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 1, false),
-    MIFFT_CFG("rows256_f64_4x8x8", double, MIFFT_F64, 256, 3, 4, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 1, false),
-    MIFFT_CFG("rows128_f64_8x4x4", double, MIFFT_F64, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_LDS, 1, false),
-    MIFFT_CFG("rows64_f64_4x4x4", double, MIFFT_F64, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_LDS, 1, false),
-    MIFFT_CFG("rows93_f64_31x3", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 32, 96, false, false, false, TW_LDS, 1, false),
-    MIFFT_CFG("rows480_f64_10x6x8", double, MIFFT_F64, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
-    MIFFT_CFG("rows640_f64_10x8x8", double, MIFFT_F64, 640, 3, 10, 8, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_CR("rows1024_f64_4x4x8x8", double, MIFFT_F64, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_CR("rows512_f64_8x8x8", double, MIFFT_F64, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_CR("rows256_f64_4x8x8", double, MIFFT_F64, 256, 3, 4, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_CR("rows128_f64_8x4x4", double, MIFFT_F64, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_CR("rows64_f64_4x4x4", double, MIFFT_F64, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_CR("rows93_f64_31x3", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 32, 96, false, false, false, TW_LDS, 1, false),
+    MIFFT_CFG_CR("rows480_f64_10x6x8", double, MIFFT_F64, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_CR("rows640_f64_10x8x8", double, MIFFT_F64, 640, 3, 10, 8, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG("cols640_f64_4x4x8x5", double, MIFFT_F64, 640, 4, 4, 4, 8, 5, 8, 256, true, true, true, TW_LDS, 1, false),
     MIFFT_CFG("cols480_f64_4x4x6x5", double, MIFFT_F64, 480, 4, 4, 4, 6, 5, 8, 256, true, true, true, TW_LDS, 1, false),
     MIFFT_CFG("cols128_f64_8x4x4", double, MIFFT_F64, 128, 3, 8, 4, 4, 1, 8, 128, true, true, true, TW_LDS, 1, false),
@@ -106,7 +53,6 @@ static int launch_plane(const Plan& plan, const DimPass& pass, const void* in, v
     tp.out = out;
     tp.tw = pass.d_twiddle;
     tp.inverse = plan.inverse;
-    tp.in_real = plan.in_components == 1 ? 1 : 0;
     tp.scale = plan.inverse ? 1.0 / ((double)pass.N * (double)pass.N1) : 1.0;
     tp.inner = CC::TILE;  // column stride inside a plane = N2
     tp.tiles_per_outer = 1;
@@ -147,7 +93,7 @@ static const PlaneEntry kPlaneTable[] = {
 };
 
 bool select_fast_plane(const Plan& plan, DimPass& pass) {
-    if (plan.in_dtype != plan.out_dtype) return false;
+    if (plan.in_dtype != plan.out_dtype || plan.in_components != 2) return false;
     for (const PlaneEntry& e : kPlaneTable) {
         if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
         pass.kernel_name = e.name;
@@ -166,9 +112,10 @@ bool select_fast(const Plan& plan, DimPass& pass) {
     // precision run on the generic family
     if (pass.first && plan.in_dtype != plan.out_dtype) return false;
     const bool cols = pass.inner != 1;
-    for (const FastEntry& e : kFastTable) {
-        if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols) continue;
-        if (cols && pass.inner < e.tile) continue;
+    auto try_entry = [&](const FastEntry& e) {
+        if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols) return false;
+        if (e.in_real != (pass.first && plan.in_components == 1)) return false;
+        if (cols && pass.inner < e.tile) return false;
         pass.kernel_name = e.name;
         pass.launch = e.launch;
         pass.tile = e.tile;
@@ -176,7 +123,13 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         pass.lds_bytes = e.lds;
         pass.ld = (int)pass.N;
         return true;
-    }
+    };
+    for (const FastEntry& e : kFastTable)  // hand-tuned entries win
+        if (try_entry(e)) return true;
+    int ngen = 0;
+    const FastEntry* gen = cols ? gen_cols_table(&ngen) : gen_rows_table(&ngen);
+    for (int i = 0; i < ngen; ++i)
+        if (try_entry(gen[i])) return true;
     return false;
 }
 

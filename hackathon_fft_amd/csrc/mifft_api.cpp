@@ -131,7 +131,7 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
     *out_plan = nullptr;
     // ---- validation = _check_layout_conditions_nd (fft/fft/fft.mojo:20-46) ----
     if (ndim < 1 || ndim > MIFFT_MAX_DIMS)
-        return set_error(MIFFT_ERR_BAD_RANK, "The rank should be bigger than 2 (1..3 transformed dims supported)");
+        return set_error(MIFFT_ERR_BAD_RANK, "The rank should be bigger than 2 (1..6 transformed dims supported)");
     if (!dims) return set_error(MIFFT_ERR_NULL, "dims is NULL");
     if (in_components < 1 || in_components > 2)
         return set_error(MIFFT_ERR_BAD_COMPONENTS, "The last dimension of in_layout should be 1 or 2");

@@ -65,7 +65,7 @@ struct Plan {
     int device = 0;
     int in_dtype = MIFFT_F32, out_dtype = MIFFT_F32;
     int ndim = 1;
-    int64_t dims[MIFFT_MAX_DIMS] = {0, 0, 0};
+    int64_t dims[MIFFT_MAX_DIMS] = {};
     int64_t batch = 0;
     int64_t prod = 1;
     int in_components = 2;

@@ -14,8 +14,8 @@
  * the reference lives in oracle/ and is test infrastructure only.
  *
  * Data layout (reference: fft/fft/fft.mojo:20-46): row-major
- *     x   : (batch, d0[, d1[, d2]], C_in)   C_in  in {1 (real), 2 (re,im)}
- *     out : (batch, d0[, d1[, d2]], 2)      interleaved (re, im)
+ *     x   : (batch, d0[, d1[, ...]], C_in)   C_in  in {1 (real), 2 (re,im)}     (1..MIFFT_MAX_DIMS dims)
+ *     out : (batch, d0[, d1[, ...]], 2)      interleaved (re, im)
  * Forward transform is unnormalised with exp(-2*pi*i*nk/N); the inverse uses
  * the conjugate twiddles and scales each transformed dimension by 1/N_dim
  * (fft/fft/_fft.mojo:292-294), i.e. matches numpy.fft.fftn / ifftn over axes
@@ -35,7 +35,7 @@ extern "C" {
 #define MIFFT_VERSION_MAJOR 0
 #define MIFFT_VERSION_MINOR 1
 
-#define MIFFT_MAX_DIMS 3
+#define MIFFT_MAX_DIMS 6
 #define MIFFT_MAX_STAGES 64
 
 /* element types (in_dtype: any of these; out_dtype: F32 or F64 only,

@@ -290,10 +290,10 @@ struct DimPlan {
 
 struct OraclePlan {
     int in_dtype, out_dtype, ndim, in_components, inverse;
-    int64_t dims[3];
+    int64_t dims[6];
     int64_t batch, prod;
     std::vector<std::vector<uint64_t>> bases;  // user (or default) bases per dim
-    void* dimplans[3] = {nullptr, nullptr, nullptr};  // DimPlan<float|double>*
+    void* dimplans[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // DimPlan<float|double>*
     std::vector<char> calc_buf;                 // _CPUPlan.calc_buf, _ndim_fft_cpu.mojo:44-45
     int64_t max_batch_prod = 0;                 // _find_max_batch_prod, :126-134
     int total_stages = 0;                       // :141-143
@@ -532,7 +532,7 @@ int mifft_oracle_plan_create(void** out_plan, int in_dtype, int out_dtype, int n
                              const int32_t* bases_len, int default_target_gpu) {
     if (!out_plan || !dims) return fail(ORA_ERR_NULL, "null argument");
     *out_plan = nullptr;
-    if (ndim < 1 || ndim > 3) return fail(ORA_ERR_BAD_RANK, "The rank should be bigger than 2 (ndim in 1..3)");
+    if (ndim < 1 || ndim > 6) return fail(ORA_ERR_BAD_RANK, "The rank should be bigger than 2 (ndim in 1..6)");
     if (in_components < 1 || in_components > 2)
         return fail(ORA_ERR_BAD_COMPONENTS, "The last dimension of in_layout should be 1 or 2");
     if (out_dtype != ORA_F32 && out_dtype != ORA_F64) return fail(ORA_ERR_BAD_DTYPE, "out_dtype must be floating point");

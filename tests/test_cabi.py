@@ -49,7 +49,7 @@ def _create(device, dims, batch=4, in_dtype=0, out_dtype=0, comps=2, bases=None)
 
 @pytest.mark.parametrize("kwargs,status", [
     (dict(dims=[]), -1),
-    (dict(dims=[4, 4, 4, 4]), -1),
+    (dict(dims=[4, 4, 4, 4, 4, 4, 4]), -1),
     (dict(dims=[1]), -2),
     (dict(dims=[8, 1]), -2),
     (dict(dims=[8], comps=3), -3),

@@ -1,0 +1,52 @@
+"""Every fused-kernel configuration emitted by tools/gen_fast_table.py, contiguous and strided,
+against fp64 pocketfft (the oracle is pinned to pocketfft at <= 6e-13 in test_oracle_golden.py and
+would take minutes at the larger lengths)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hackathon_fft_amd as mf
+from conftest import REL_L2_TOL_F32, ROOT, from_complex, rel_l2, to_complex
+
+pytestmark = pytest.mark.gpu
+
+_spec = importlib.util.spec_from_file_location("gen_fast_table", os.path.join(ROOT, "tools", "gen_fast_table.py"))
+_gen = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_gen)
+
+
+def _run(x_np):
+    x = torch.from_numpy(x_np).to("cuda:0")
+    out = torch.full_like(x, float("nan"))
+    ctx = mf.DeviceContext(0)
+    plan = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, ctx=ctx)
+    mf.fft(out, x, ctx, plan=plan)
+    ctx.synchronize()
+    return out.cpu().numpy(), plan
+
+
+@pytest.mark.parametrize("n", _gen.SIZES)
+def test_rows(n):
+    rng = np.random.default_rng(n)
+    batch = 131 if n <= 512 else 7      # ragged against every tile size
+    x = rng.standard_normal((batch, n, 2)).astype(np.float32)
+    out, plan = _run(x)
+    assert not np.isnan(out).any()
+    truth = np.fft.fft(to_complex(x), axis=1)
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32, plan.kernel_name(0)
+    assert plan.kernel_name(0) != "generic", n
+
+
+@pytest.mark.parametrize("n", [s for s in _gen.SIZES if s <= 4096])
+def test_cols(n):
+    rng = np.random.default_rng(n + 1)
+    inner = 40                          # not a multiple of the 16-column tile: ragged last tile
+    x = rng.standard_normal((2, n, inner, 2)).astype(np.float32)
+    out, plan = _run(x)
+    assert not np.isnan(out).any()
+    truth = np.fft.fftn(to_complex(x), axes=(1, 2))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32, plan.kernel_name(0)
+    assert plan.kernel_name(0) != "generic", n

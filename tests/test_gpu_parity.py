@@ -98,6 +98,8 @@ BASELINE_CASES = [
     ((5, 256), None),
     ((9, 64), None),
     ((5, 16, 12, 10), None),
+    ((2, 6, 8, 10, 12), None),   # 4 transformed dims
+    ((1, 3, 4, 64, 64), None),
     ((130, 480), None),
     ((90, 640), None),
     ((7, 4096), None),

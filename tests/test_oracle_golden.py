@@ -78,6 +78,16 @@ def test_fp32_baseline_shapes_vs_pocketfft(shape, bases):
     assert rel_l2(back, x) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 4, 6, 5, 8), (1, 3, 4, 2, 5, 6)])
+def test_rank_above_three_like_the_reference_allows(shape):
+    # the reference's layout check only asks for rank > 2 (fft/fft/fft.mojo:22-26); its bench lists 4-D shapes
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(shape + (2,))
+    out = O.fftn(x)
+    ref = np.fft.fftn(to_complex(x), axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(ref, np.float64)) < 1e-13
+
+
 def test_threads_do_not_change_results():
     rng = np.random.default_rng(7)
     x = rng.standard_normal((5, 12, 10, 2)).astype(np.float32)

@@ -45,7 +45,6 @@ Variant make(const char* name) {
         tp.out = out;
         tp.tw = tw;
         tp.inverse = 0;
-        tp.in_real = 0;
         tp.scale = 1.0;
         if (C::COLS) {
             tp.inner = inner;
@@ -80,7 +79,6 @@ Variant make_plane(const char* name) {
         tp.out = out;
         tp.tw = tw;
         tp.inverse = 0;
-        tp.in_real = 0;
         tp.scale = 1.0;
         tp.inner = CC::TILE;
         tp.tiles_per_outer = 1;
