@@ -114,7 +114,17 @@ def cpu_baseline(shape, bases, budget_s=12.0):
     }
 
 
+def _claim_stdout():
+    """Keep stdout clean for the ONE JSON line: native libraries (RCCL prints a version banner on
+    init) write to fd 1 directly, so fd 1 is pointed at stderr and the JSON goes to the saved fd."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(saved, "w")
+
+
 def main():
+    json_out = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -131,7 +141,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # MIFFT_BENCH_FORCE_DIST=1 runs the RCCL code path even with one rank (1-GPU rehearsal of the N>1 launch)
+    distributed = world > 1 or os.environ.get("MIFFT_BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libmifft has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -231,7 +242,8 @@ def main():
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(shape, bases)
-        print(json.dumps(result), flush=True)
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

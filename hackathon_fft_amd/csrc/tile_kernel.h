@@ -58,7 +58,7 @@ enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
 
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
-          bool IN_REAL_ = false>
+          bool IN_REAL_ = false, bool DMA_ = false>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -90,7 +90,13 @@ struct TileCfg {
     }
     static constexpr int TWL_TOTAL = TWMODE_ == TW_LDS ? TWL_OFF(NP_) : 0;
     static constexpr int DATA_ELEMS = COLS_ ? N_ * TILE_ : LD * TILE_;
-    static constexpr size_t LDS_BYTES = (size_t)(DATA_ELEMS + TWL_TOTAL) * 2 * sizeof(T_);
+    // DMA: the flat HBM -> LDS copy of the NEXT tile runs asynchronously (global_load_lds) into a staging
+    // buffer behind the twiddle table while this tile's passes execute
+    static constexpr bool DMA = DMA_;
+    static constexpr int STAGE_OFF = ((DATA_ELEMS + TWL_TOTAL) * 2 * (int)sizeof(T_) + 15) / 16 * 16 / (2 * (int)sizeof(T_));
+    static constexpr int STAGE_ELEMS = DMA_ ? N_ * TILE_ : 0;
+    static constexpr size_t LDS_BYTES =
+        DMA_ ? (size_t)(STAGE_OFF + STAGE_ELEMS) * 2 * sizeof(T_) : (size_t)(DATA_ELEMS + TWL_TOTAL) * 2 * sizeof(T_);
     static_assert(P(NP_) == N_, "radices must multiply to N");
 };
 
@@ -222,21 +228,101 @@ MIFFT_DEV void load_pass0(const TileParams& p, cpx<typename C::T> (*v)[C::R(0)],
     }
 }
 
+// workgroup barrier.  Kernels with an LDS-DMA in flight (C::DMA) must not use __syncthreads(): its fence
+// drains vmcnt and with it the asynchronous copy (cdna_hip_programming.md, "Pipelining across barriers").
+template <class C>
+MIFFT_DEV void wg_barrier() {
+    if constexpr (C::DMA)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else
+        __syncthreads();
+}
+
+// LDS -> registers: the R inputs of every butterfly this thread owns in pass I, twiddled
+template <class C, int I>
+MIFFT_DEV void pass_gather_lds(const TileParams& p, const cpx<typename C::T>* src, const cpx<typename C::T>* ltw,
+                               const cpx<typename C::T>* twr, cpx<typename C::T> (*v)[C::R(I)], int tid) {
+    using T = typename C::T;
+    using V = cpx<T>;
+    constexpr int R = C::R(I), P = C::P(I), NB = C::NB(I), IPT = C::IPT(I), RATIO = C::N / (P * R);
+    constexpr bool EXACT = C::ITEMS(I) % C::THREADS == 0;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int id = tid + k * C::THREADS;
+        if (EXACT || id < C::ITEMS(I)) {
+            int c, b;
+            item_decode<C, I>(id, c, b);
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[k][j] = src[lds_index<C, I - 1>(c, b + j * NB)];
+            if constexpr (I > 0) {
+                const int pp = b % P;
+#pragma unroll
+                for (int j = 1; j < R; ++j) {
+                    V w;
+                    if constexpr (C::TWMODE == TW_REG) {
+                        w = twr[C::TW_OFF(I) + k * (R - 1) + (j - 1)];
+                    } else if constexpr (C::TWMODE == TW_LDS) {
+                        w = ltw[C::TWL_OFF(I) + (j - 1) * P + pp];
+                    } else {
+                        w = ((const V*)p.tw)[j * pp * RATIO];
+                        if (p.inverse) w.y = -w.y;
+                    }
+                    v[k][j] = cmul(v[k][j], w);
+                }
+            }
+        }
+    }
+}
+
+// registers -> butterflies -> Stockham scatter (LDS, or HBM for the last pass)
+template <class C, int I>
+MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds, cpx<typename C::T> (*v)[C::R(I)],
+                                    long long base, int nv, int tid) {
+    using T = typename C::T;
+    using V = cpx<T>;
+    constexpr int R = C::R(I), P = C::P(I), IPT = C::IPT(I);
+    constexpr bool EXACT = C::ITEMS(I) % C::THREADS == 0;
+    constexpr bool DST_GLOBAL = (I == C::NP - 1) && C::LAST_DIRECT;
+    V* gout = (V*)p.out;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int id = tid + k * C::THREADS;
+        if (EXACT || id < C::ITEMS(I)) {
+            int c, b;
+            item_decode<C, I>(id, c, b);
+            Dft<R, T, 1>::run(v[k]);
+            const int q = b / P, pp = b - q * P;
+            const int o0 = q * P * R + pp;
+            if constexpr (DST_GLOBAL) {
+                if (c < nv) {
+#pragma unroll
+                    for (int s = 0; s < R; ++s) {
+                        V y = v[k][s];
+                        if (p.inverse) {
+                            y.x *= (T)p.scale;
+                            y.y *= -(T)p.scale;
+                        }
+                        gout[gaddr<C>(p, base, c, o0 + s * P)] = y;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < R; ++s) lds[lds_index<C, I>(c, o0 + s * P)] = v[k][s];
+            }
+        }
+    }
+}
+
 template <class C, int I>
 MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<typename C::T>* twr,
                         cpx<typename C::T> (*pre)[C::R(0)], long long base, int nv, int tid) {
     if constexpr (I < C::NP) {
         using T = typename C::T;
         using V = cpx<T>;
-        constexpr int R = C::R(I), P = C::P(I), NB = C::NB(I), IPT = C::IPT(I), RATIO = C::N / (P * R);
-        constexpr bool EXACT = C::ITEMS(I) % C::THREADS == 0;
+        constexpr int R = C::R(I), IPT = C::IPT(I);
         constexpr bool SRC_GLOBAL = (I == 0) && C::FIRST_DIRECT;
         constexpr bool DST_GLOBAL = (I == C::NP - 1) && C::LAST_DIRECT;
         V v[IPT][R];
-        V* gout = (V*)p.out;
-        const V* ltw = lds + C::DATA_ELEMS;
-
-        // ---- gather the R inputs of every butterfly this thread owns ----
         if constexpr (SRC_GLOBAL) {
             if constexpr (C::PREFETCH) {
 #pragma unroll
@@ -253,66 +339,13 @@ MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<
                     for (int j = 0; j < R; ++j) v[k][j].y = -v[k][j].y;
             }
         } else {
-#pragma unroll
-            for (int k = 0; k < IPT; ++k) {
-                const int id = tid + k * C::THREADS;
-                if (EXACT || id < C::ITEMS(I)) {
-                    int c, b;
-                    item_decode<C, I>(id, c, b);
-#pragma unroll
-                    for (int j = 0; j < R; ++j) v[k][j] = lds[lds_index<C, I - 1>(c, b + j * NB)];
-                    if constexpr (I > 0) {
-                        const int pp = b % P;
-#pragma unroll
-                        for (int j = 1; j < R; ++j) {
-                            V w;
-                            if constexpr (C::TWMODE == TW_REG) {
-                                w = twr[C::TW_OFF(I) + k * (R - 1) + (j - 1)];
-                            } else if constexpr (C::TWMODE == TW_LDS) {
-                                w = ltw[C::TWL_OFF(I) + (j - 1) * P + pp];
-                            } else {
-                                w = ((const V*)p.tw)[j * pp * RATIO];
-                                if (p.inverse) w.y = -w.y;
-                            }
-                            v[k][j] = cmul(v[k][j], w);
-                        }
-                    }
-                }
-            }
+            pass_gather_lds<C, I>(p, lds, lds + C::DATA_ELEMS, twr, v, tid);
             // in-place LDS buffer: every read of this pass completes before any later write (this
             // pass's scatter, or pass 0 of the NEXT tile when this pass stores to HBM)
-            __syncthreads();
+            wg_barrier<C>();
         }
-
-        // ---- butterflies + Stockham scatter ----
-#pragma unroll
-        for (int k = 0; k < IPT; ++k) {
-            const int id = tid + k * C::THREADS;
-            if (EXACT || id < C::ITEMS(I)) {
-                int c, b;
-                item_decode<C, I>(id, c, b);
-                Dft<R, T, 1>::run(v[k]);
-                const int q = b / P, pp = b - q * P;
-                const int o0 = q * P * R + pp;
-                if constexpr (DST_GLOBAL) {
-                    if (c < nv) {
-#pragma unroll
-                        for (int s = 0; s < R; ++s) {
-                            V y = v[k][s];
-                            if (p.inverse) {
-                                y.x *= (T)p.scale;
-                                y.y *= -(T)p.scale;
-                            }
-                            gout[gaddr<C>(p, base, c, o0 + s * P)] = y;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < R; ++s) lds[lds_index<C, I>(c, o0 + s * P)] = v[k][s];
-                }
-            }
-        }
-        if constexpr (!DST_GLOBAL) __syncthreads();
+        pass_compute_scatter<C, I>(p, lds, v, base, nv, tid);
+        if constexpr (!DST_GLOBAL) wg_barrier<C>();
         run_pass<C, I + 1>(p, lds, twr, pre, base, nv, tid);
     }
 }
@@ -395,6 +428,98 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// tile_kernel_dma<C>: the flat-copy configurations (rows that are not 16-byte aligned, e.g. N = 93)
+// with an asynchronous HBM -> LDS copy.  While the passes of tile t run in the work buffer, the
+// rows of tile t+1 stream into a staging buffer by LDS-DMA (global_load_lds_dwordx4: per-lane
+// source address, LDS destination = wave-uniform base + lane*16, no VGPRs), so the workgroup
+// always has a whole tile of HBM reads in flight.  Pass 0 reads the staging buffer and scatters
+// into the work buffer; the copy of the next tile is issued as soon as every wave has gathered.
+// Requires a 16-byte aligned tile base (checked by the launcher; otherwise tile_kernel<C> runs).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* mifft_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* mifft_glb_ptr_t;
+
+template <class C>
+MIFFT_DEV void dma_issue_tile(const TileParams& p, cpx<typename C::T>* stage, long long base, int nv, int tid) {
+    using V = cpx<typename C::T>;
+    constexpr int PER16 = 16 / (int)sizeof(V);            // complex elements per 16-byte piece
+    const int pieces = (nv * C::N) / PER16;               // launcher guarantees nv*N*sizeof(V) % 16 == 0
+    const char* g = (const char*)((const V*)p.in + base);
+    const int lane = tid & 63, wave0 = tid - lane;  // first thread of this wave (the last wave may be partial)
+    for (int w0 = wave0; w0 < pieces; w0 += C::THREADS) {
+        const int idx = w0 + lane;
+        if (idx < pieces)
+            __builtin_amdgcn_global_load_lds((mifft_glb_ptr_t)(g + (size_t)idx * 16),
+                                             (mifft_lds_ptr_t)((char*)stage + (size_t)w0 * 16), 16, 0, 0);
+    }
+    // odd element count (a ragged last tile of odd-length rows): the trailing 8 bytes go the ordinary way
+    if (PER16 == 2 && ((nv * C::N) & 1) && tid == 0) stage[nv * C::N - 1] = ((const V*)p.in)[base + nv * C::N - 1];
+}
+
+template <class C>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel_dma(const TileParams p) {
+    using T = typename C::T;
+    using V = cpx<T>;
+    static_assert(C::DMA && !C::COLS && !C::FIRST_DIRECT && !C::LAST_DIRECT && !C::IN_REAL && C::LD == C::N,
+                  "DMA staging is for the flat-copy row configurations");
+    static_assert(C::TWMODE != TW_REG, "register twiddles not wired for the DMA variant");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V* lds = (V*)smem;
+    V* stage = lds + C::STAGE_OFF;
+    const int tid = threadIdx.x;
+    V twr[1];
+    if constexpr (C::TWMODE == TW_LDS) fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, tid, p.inverse);
+
+    long long t = blockIdx.x;
+    if (t < p.n_tiles) {
+        long long base;
+        int nv;
+        tile_geom<C>(p, t, base, nv);
+        dma_issue_tile<C>(p, stage, base, nv, tid);
+    }
+    for (; t < p.n_tiles; t += gridDim.x) {
+        long long base;
+        int nv;
+        tile_geom<C>(p, t, base, nv);
+        // this wave's share of the copy has landed (and its previous stores have drained) ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg_barrier<C>();  // ... and so has every other wave's; nobody still reads the work buffer
+        constexpr int R0 = C::R(0), IPT0 = C::IPT(0);
+        V v[IPT0][R0];
+        pass_gather_lds<C, 0>(p, stage, lds + C::DATA_ELEMS, twr, v, tid);
+        if (p.inverse) {
+#pragma unroll
+            for (int k = 0; k < IPT0; ++k)
+#pragma unroll
+                for (int j = 0; j < R0; ++j) v[k][j].y = -v[k][j].y;
+        }
+        wg_barrier<C>();  // staging buffer fully consumed
+        const long long tn = t + gridDim.x;
+        if (tn < p.n_tiles) {
+            long long nbase;
+            int nnv;
+            tile_geom<C>(p, tn, nbase, nnv);
+            dma_issue_tile<C>(p, stage, nbase, nnv, tid);  // overlaps with everything below
+        }
+        pass_compute_scatter<C, 0>(p, lds, v, base, nv, tid);
+        wg_barrier<C>();
+        V none[1][R0];
+        run_pass<C, 1>(p, lds, twr, none, base, nv, tid);
+        // flat coalesced LDS -> HBM store of the finished tile
+        V* gout = (V*)p.out;
+        const int total = nv * C::N;
+        for (int f = tid; f < total; f += C::THREADS) {
+            V y = lds[f];  // last exchange is natural order, LD == N
+            if (p.inverse) {
+                y.x *= (T)p.scale;
+                y.y *= -(T)p.scale;
+            }
+            gout[base + f] = y;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // plane_kernel<CR, CC>: the two innermost dimensions (N1 x N2, N2 contiguous) of one 2-D slice are

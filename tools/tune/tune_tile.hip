@@ -68,6 +68,34 @@ Variant make(const char* name) {
     return v;
 }
 
+template <class C>
+Variant make_dma(const char* name) {
+    Variant v;
+    v.name = name;
+    v.lds = C::LDS_BYTES;
+    v.run = [](const void* in, void* out, const void* tw, long long batch, long long outer, long long inner) {
+        TileParams tp{};
+        tp.in = in;
+        tp.out = out;
+        tp.tw = tw;
+        tp.inverse = 0;
+        tp.scale = 1.0;
+        tp.n_rows = batch * outer;
+        tp.inner = 1;
+        tp.tiles_per_outer = 1;
+        tp.n_tiles = (tp.n_rows + C::TILE - 1) / C::TILE;
+        auto k = tile_kernel_dma<C>;
+        static bool set = false;
+        if (!set && C::LDS_BYTES > 64 * 1024) {
+            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+            set = true;
+        }
+        long long grid = tile_grid<C>(g_cus, tp.n_tiles, g_wg_override);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), C::LDS_BYTES, 0, tp);
+    };
+    return v;
+}
+
 template <class CR, class CC>
 Variant make_plane(const char* name) {
     Variant v;
@@ -96,6 +124,9 @@ Variant make_plane(const char* name) {
 }
 
 #define V(NAME, ...) make<TileCfg<__VA_ARGS__>>(NAME)
+// DMA-staged flat-copy rows: T N NP R0..R3 TILE THREADS TWMODE MINW
+#define D(NAME, T, N, NP, R0, R1, R2, R3, TILE, THR, TWM, MINW) \
+    make_dma<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THR, false, false, false, TWM, MINW, false, 0, false, true>>(NAME)
 #define PL(NAME, THR, MINW, PF, R0, R1, R2, R3, NP)                                                              \
     make_plane<TileCfg<float, 128, NP, R0, R1, R2, R3, 128, THR, false, true, false, TW_LDS, MINW, PF>,          \
                TileCfg<float, 128, NP, R0, R1, R2, R3, 128, THR, true, false, true, TW_LDS, MINW, false>>(NAME)
@@ -141,16 +172,15 @@ int main(int argc, char** argv) {
     const long long batch = 500000, outer = 1, inner = 1;
     const int N = 93;
     std::vector<Variant> vs = {
-        V("31x3 t64 192 glb w1", float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_GLOBAL, 1, false),
-        V("31x3 t64 192 glb w2", float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_GLOBAL, 2, false),
-        V("31x3 t64 192 lds w2", float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 2, false),
         V("31x3 t64 192 lds w3", float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        V("31x3 t32 96 lds w2", float, 93, 2, 31, 3, 1, 1, 32, 96, false, false, false, TW_LDS, 2, false),
-        V("31x3 t128 384 lds w2", float, 93, 2, 31, 3, 1, 1, 128, 384, false, false, false, TW_LDS, 2, false),
-        V("31x3 t64 64 lds w2", float, 93, 2, 31, 3, 1, 1, 64, 64, false, false, false, TW_LDS, 2, false),
-        V("31x3 t64 128 lds w2", float, 93, 2, 31, 3, 1, 1, 64, 128, false, false, false, TW_LDS, 2, false),
-        V("31x3 t64 256 lds w2", float, 93, 2, 31, 3, 1, 1, 64, 256, false, false, false, TW_LDS, 2, false),
-        V("3x31 t64 192 lds w2", float, 93, 2, 3, 31, 1, 1, 64, 192, false, false, false, TW_LDS, 2, false),
+        D("dma 31x3 t64 192 lds w3", float, 93, 2, 31, 3, 1, 1, 64, 192, TW_LDS, 3),
+        D("dma 31x3 t32 96 lds w3", float, 93, 2, 31, 3, 1, 1, 32, 96, TW_LDS, 3),
+        D("dma 31x3 t32 128 lds w3", float, 93, 2, 31, 3, 1, 1, 32, 128, TW_LDS, 3),
+        D("dma 31x3 t64 256 lds w3", float, 93, 2, 31, 3, 1, 1, 64, 256, TW_LDS, 3),
+        D("dma 31x3 t64 192 lds w2", float, 93, 2, 31, 3, 1, 1, 64, 192, TW_LDS, 2),
+        D("dma 31x3 t48 192 lds w3", float, 93, 2, 31, 3, 1, 1, 48, 192, TW_LDS, 3),
+        D("dma 31x3 t64 192 glb w3", float, 93, 2, 31, 3, 1, 1, 64, 192, TW_GLOBAL, 3),
+        D("dma 3x31 t64 192 lds w3", float, 93, 2, 3, 31, 1, 1, 64, 192, TW_LDS, 3),
     };
 #elif GROUP == 3  // ---- 500k x 128 rows (config 1 shape, config 5 z axis) ----
     const long long batch = 500000, outer = 1, inner = 1;
