@@ -45,7 +45,8 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
 // configuration table.  NP, R0..R3, TILE, THREADS, COLS, FIRST_DIRECT, LAST_DIRECT, TWMODE, MINW, PREFETCH
 // ---------------------------------------------------------------------------------------------
 struct FastEntry {
-    bool in_real;  // the kernel promotes a real (C_in = 1) tensor in its pass-0 load
+    bool in_real;     // the kernel promotes a real (C_in = 1) tensor in its pass-0 load
+    int stream_pref;  // 1: only for streaming-size problems (non-temporal twin), -1: any size
     int out_dtype;
     int N;
     bool cols;
@@ -55,16 +56,21 @@ struct FastEntry {
     size_t lds;
 };
 
-#define MIFFT_CFG_X(REAL, NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                         \
+#define MIFFT_CFG_X(REAL, NTM, STREAM, NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                         \
     {                                                                                                               \
-        REAL, DT, N, COLS, NAME, launch_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL>>,   \
-            TILE, THREADS, TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL>::LDS_BYTES       \
+        REAL, STREAM, DT, N, COLS, NAME, launch_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM>>,   \
+            TILE, THREADS, TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM>::LDS_BYTES       \
     }
 
 
-#define MIFFT_CFG(...) MIFFT_CFG_X(false, __VA_ARGS__)
+#define MIFFT_CFG(...) MIFFT_CFG_X(false, 0, -1, __VA_ARGS__)
 // complex-input kernel + its real-input twin (contiguous dimension only)
-#define MIFFT_CFG_CR(NAME, ...) MIFFT_CFG_X(false, NAME, __VA_ARGS__), MIFFT_CFG_X(true, NAME "_r", __VA_ARGS__)
+#define MIFFT_CFG_CR(NAME, ...) \
+    MIFFT_CFG_X(false, 0, -1, NAME, __VA_ARGS__), MIFFT_CFG_X(true, 0, -1, NAME "_r", __VA_ARGS__)
+// non-temporal twin for problems that dwarf the Infinity Cache (listed BEFORE the plain entry)
+#define MIFFT_CFG_STREAM(NAME, ...) MIFFT_CFG_X(false, 3, 1, NAME "_nt", __VA_ARGS__)
+// ... with non-temporal stores only (tiles staged through a flat LDS copy re-read their lines)
+#define MIFFT_CFG_STREAM_ST(NAME, ...) MIFFT_CFG_X(false, 2, 1, NAME "_nts", __VA_ARGS__)
 
 // tables instantiated in kernels_fast_gen_rows.hip / kernels_fast_gen_cols.hip (host-only data:
 // kept TU-local there so that the device pass never sees the host launcher pointers)

@@ -12,9 +12,19 @@
 
 #include <hip/hip_runtime.h>
 
+// Results must not depend on which tile slot / unrolled code instance a transform lands in (a slab of
+// the batch must equal the same rows of the whole batch bit for bit, also across GPUs), so the compiler
+// may not choose where to contract a*b+c: contraction is off and every FMA below is explicit.
+#ifndef MIFFT_ALLOW_CONTRACT
+#pragma clang fp contract(off)
+#endif
+
 namespace mifft {
 
 #define MIFFT_DEV __host__ __device__ __forceinline__
+
+MIFFT_DEV float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+MIFFT_DEV double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 template <typename T>
 struct alignas(2 * sizeof(T)) cpx {
@@ -24,7 +34,11 @@ struct alignas(2 * sizeof(T)) cpx {
 template <typename T> MIFFT_DEV cpx<T> operator+(cpx<T> a, cpx<T> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename T> MIFFT_DEV cpx<T> operator-(cpx<T> a, cpx<T> b) { return {a.x - b.x, a.y - b.y}; }
 template <typename T> MIFFT_DEV cpx<T> cmul(cpx<T> a, cpx<T> b) {
+#ifdef MIFFT_EXPLICIT_FMA
+    return {fma_t(a.x, b.x, -(a.y * b.y)), fma_t(a.x, b.y, a.y * b.x)};
+#else
     return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+#endif
 }
 template <typename T> MIFFT_DEV cpx<T> mul_neg_i(cpx<T> a) { return {a.y, -a.x}; }  // a * (-i)
 template <typename T> MIFFT_DEV cpx<T> mul_pos_i(cpx<T> a) { return {-a.y, a.x}; }  // a * (+i)
@@ -111,7 +125,11 @@ MIFFT_DEV cpx<T> mul_w(cpx<T> v) {
     } else {
         constexpr cx_pair cs = cx_cossin(NUM, DEN);
         constexpr T c = (T)cs.c, s = (T)(-cs.s);  // exp(-i a) = cos a - i sin a
+#ifdef MIFFT_EXPLICIT_FMA
+        return {fma_t(v.x, c, -(v.y * s)), fma_t(v.x, s, v.y * c)};
+#else
         return {v.x * c - v.y * s, v.x * s + v.y * c};
+#endif
     }
 }
 
@@ -163,10 +181,17 @@ struct DftOddPrime {
         if constexpr (j <= H) {
             constexpr cx_pair cs = cx_cossin((long long)j * s, R);
             constexpr T c = (T)cs.c, sn = (T)cs.s;
+#ifndef MIFFT_NO_PRIME_FMA
+            A.x = fma_t(c, a[j - 1].x, A.x);
+            A.y = fma_t(c, a[j - 1].y, A.y);
+            B.x = fma_t(sn, b[j - 1].x, B.x);
+            B.y = fma_t(sn, b[j - 1].y, B.y);
+#else
             A.x += c * a[j - 1].x;
             A.y += c * a[j - 1].y;
             B.x += sn * b[j - 1].x;
             B.y += sn * b[j - 1].y;
+#endif
             acc<s, j + 1>(a, b, A, B);
         }
     }

@@ -9,15 +9,20 @@ static const FastEntry kFastTable[] = {
     // DESIGN.md).  Forcing more waves/SIMD than the butterflies' live registers allow spills and
     // loses 2-3x, so MINW is only raised where the kernel fits.
     // ---- contiguous dimension, fp32 ----
-    MIFFT_CFG_CR("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
-    MIFFT_CFG_CR("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
-    MIFFT_CFG_CR("rows256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, false, true, true, TW_REG, 2, true),
+    // 1024: LDS twiddles at 4 waves/SIMD.  (Register twiddles + prefetch measured the same 0.299 ms but sit on
+    // the 256-VGPR edge: a refactor that added 20 B of scratch doubled their time.)
+    MIFFT_CFG_STREAM("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+    MIFFT_CFG_CR("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+    MIFFT_CFG_CR("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+    MIFFT_CFG_CR("rows256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_STREAM("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_CR("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_CR("rows64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_CR("rows2048_16x16x8", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
     // one 128-KiB row per workgroup; twiddles from the global table (the compact LDS table would need 131 KB more)
     MIFFT_CFG("rows16384_16x16x8x8", float, MIFFT_F32, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, false),
+    MIFFT_CFG_STREAM_ST("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
     MIFFT_CFG_CR("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
     MIFFT_CFG_CR("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_CR("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
@@ -112,9 +117,12 @@ bool select_fast(const Plan& plan, DimPass& pass) {
     // precision run on the generic family
     if (pass.first && plan.in_dtype != plan.out_dtype) return false;
     const bool cols = pass.inner != 1;
+    // read + write volume of one exec far beyond the 256-MB Infinity Cache -> non-temporal twins apply
+    const bool streaming = (double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0 > 0.6e9;
     auto try_entry = [&](const FastEntry& e) {
         if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols) return false;
         if (e.in_real != (pass.first && plan.in_components == 1)) return false;
+        if (e.stream_pref == 1 && !streaming) return false;
         if (cols && pass.inner < e.tile) return false;
         pass.kernel_name = e.name;
         pass.launch = e.launch;

@@ -35,6 +35,36 @@
 
 namespace mifft {
 
+template <typename T> struct native_vec2;
+template <> struct native_vec2<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct native_vec2<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
+template <bool NT, typename T>
+MIFFT_DEV cpx<T> gload(const cpx<T>* p) {
+    if constexpr (NT) {
+        typename native_vec2<T>::type v = __builtin_nontemporal_load((const typename native_vec2<T>::type*)p);
+        return {v.x, v.y};
+    } else {
+        return *p;
+    }
+}
+template <bool NT, typename T>
+MIFFT_DEV T gload_real(const T* p) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+template <bool NT, typename T>
+MIFFT_DEV void gstore(cpx<T>* p, cpx<T> v) {
+    if constexpr (NT) {
+        typename native_vec2<T>::type w = {v.x, v.y};
+        __builtin_nontemporal_store(w, (typename native_vec2<T>::type*)p);
+    } else {
+        *p = v;
+    }
+}
+
 struct TileParams {
     const void* in;
     void* out;
@@ -58,7 +88,7 @@ enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
 
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
-          bool IN_REAL_ = false, bool DMA_ = false>
+          bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -67,6 +97,12 @@ struct TileCfg {
     // pass 0 reads a REAL tensor (C_in = 1) and promotes it (fft/fft/_fft.mojo:254-255).  Compile-time:
     // a runtime switch inside the prefetching load loop cost 0.30 -> 0.49 ms at 100k x 1024.
     static constexpr bool IN_REAL = IN_REAL_;
+    // non-temporal HBM accesses (bit 0: loads, bit 1: stores).  A tile is read once and written once; the
+    // streaming hint lifts a row-shaped copy from ~5.85 to ~6.4 TB/s on MI355X (tools/micro/copy_nt.hip) when
+    // the tensors dwarf the 256-MB Infinity Cache, and HURTS cache-resident or in-place passes (measured:
+    // N = 93 flat copy 0.173 -> 0.247 ms, 640-point column tiles 0.114 -> 0.139 ms), so it is a twin
+    // configuration chosen at plan time by tensor size.
+    static constexpr int NT = NT_;
     static constexpr int LD = N_ + ROWPAD_;  // ROWS: LDS pitch of one transform
     static constexpr int R(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : i == 2 ? R2_ : R3_; }
     static constexpr int P(int i) {
@@ -212,17 +248,18 @@ MIFFT_DEV void load_pass0(const TileParams& p, cpx<typename C::T> (*v)[C::R(0)],
         if (EXACT || id < C::ITEMS(0)) {
             int c, b;
             item_decode<C, 0>(id, c, b);
-            const bool ok = c < nv;
+            // No predicate on the loads: a slot beyond the ragged end of the last tile re-reads the last valid
+            // transform (always in bounds; its results are never stored).  Branch-free loads stay back to back
+            // with a single wait at first use -- per-load exec-masked blocks cost 40 % on the column tiles.
+            const int cc = c < nv ? c : nv - 1;
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                V x = {(T)0, (T)0};
-                if (ok) {
-                    if constexpr (C::IN_REAL)
-                        x.x = ((const T*)p.in)[gaddr<C>(p, base, c, b + j * NB)];
-                    else
-                        x = gin[gaddr<C>(p, base, c, b + j * NB)];
+                if constexpr (C::IN_REAL) {
+                    v[k][j].x = gload_real<(C::NT & 1) != 0>((const T*)p.in + gaddr<C>(p, base, cc, b + j * NB));
+                    v[k][j].y = (T)0;
+                } else {
+                    v[k][j] = gload<(C::NT & 1) != 0>(gin + gaddr<C>(p, base, cc, b + j * NB));
                 }
-                v[k][j] = x;
             }
         }
     }
@@ -302,7 +339,7 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
                             y.x *= (T)p.scale;
                             y.y *= -(T)p.scale;
                         }
-                        gout[gaddr<C>(p, base, c, o0 + s * P)] = y;
+                        gstore<(C::NT & 2) != 0>(gout + gaddr<C>(p, base, c, o0 + s * P), y);
                     }
                 }
             } else {
@@ -401,9 +438,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                 const int c = f / C::N, n = f - c * C::N;
                 V x = {(T)0, (T)0};
                 if constexpr (C::IN_REAL)
-                    x.x = ((const T*)p.in)[base + f];
+                    x.x = gload_real<(C::NT & 1) != 0>((const T*)p.in + base + f);
                 else
-                    x = gin[base + f];
+                    x = gload<(C::NT & 1) != 0>(gin + base + f);
                 if (p.inverse) x.y = -x.y;
                 lds[lds_index<C, -1>(c, n)] = x;
             }
@@ -421,7 +458,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                     y.x *= (T)p.scale;
                     y.y *= -(T)p.scale;
                 }
-                gout[base + f] = y;
+                gstore<(C::NT & 2) != 0>(gout + base + f, y);
             }
             __syncthreads();
         }
@@ -516,7 +553,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel_dma(const Til
                 y.x *= (T)p.scale;
                 y.y *= -(T)p.scale;
             }
-            gout[base + f] = y;
+            gstore<(C::NT & 2) != 0>(gout + base + f, y);
         }
     }
 }

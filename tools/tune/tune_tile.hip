@@ -124,6 +124,8 @@ Variant make_plane(const char* name) {
 }
 
 #define V(NAME, ...) make<TileCfg<__VA_ARGS__>>(NAME)
+// explicit non-temporal mode: ... PF, then NT (0 none, 1 loads, 2 stores, 3 both)
+#define VN(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, false, false, NT>>(NAME)
 // DMA-staged flat-copy rows: T N NP R0..R3 TILE THREADS TWMODE MINW
 #define D(NAME, T, N, NP, R0, R1, R2, R3, TILE, THR, TWM, MINW) \
     make_dma<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THR, false, false, false, TWM, MINW, false, 0, false, true>>(NAME)
@@ -141,46 +143,29 @@ int main(int argc, char** argv) {
     const long long batch = 100000, outer = 1, inner = 1;
     const int N = 1024;
     std::vector<Variant> vs = {
-        //              T      N    NP R0 R1 R2 R3 TILE THR COLS  FD    LD    TWMODE   MINW PF
-        V("16x8x8 t4 reg w1", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 1, false),
-        V("16x8x8 t4 reg w2", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, false),
-        V("16x8x8 t4 reg w3", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 3, false),
-        V("16x8x8 t4 reg w4", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 4, false),
-        V("16x8x8 t4 glb w4", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_GLOBAL, 4, false),
-        V("16x8x8 t4 lds w4", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
-        V("16x8x8 t4 lds w3", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 3, false),
-        V("16x8x8 t4 reg w2 pf", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
-        V("16x8x8 t4 reg w3 pf", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 3, true),
-        V("16x8x8 t4 lds w3 pf", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 3, true),
-        V("16x8x8 t4 lds w4 pf", float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, true),
-        V("16x8x8 t1 reg w2", float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_REG, 2, false),
-        V("16x8x8 t1 reg w3", float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_REG, 3, false),
-        V("16x8x8 t1 lds w4", float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_LDS, 4, false),
-        V("16x8x8 t1 reg w3 pf", float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_REG, 3, true),
-        V("16x8x8 t1 lds w4 pf", float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_LDS, 4, true),
-        V("16x8x8 t2 reg w3", float, 1024, 3, 16, 8, 8, 1, 2, 128, false, true, true, TW_REG, 3, false),
-        V("16x8x8 t2 lds w4 pf", float, 1024, 3, 16, 8, 8, 1, 2, 128, false, true, true, TW_LDS, 4, true),
-        V("8x16x8 t4 reg w3", float, 1024, 3, 8, 16, 8, 1, 4, 256, false, true, true, TW_REG, 3, false),
-        V("8x8x16 t4 reg w3", float, 1024, 3, 8, 8, 16, 1, 4, 256, false, true, true, TW_REG, 3, false),
-        V("4x4x8x8 t2 reg w4", float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_REG, 4, false),
-        V("4x4x8x8 t2 reg w5", float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_REG, 5, false),
-        V("4x4x8x8 t2 reg w4 pf", float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_REG, 4, true),
-        V("32x32 t8 lds w2", float, 1024, 2, 32, 32, 1, 1, 8, 256, false, true, true, TW_LDS, 2, false),
-        V("32x32 t8 lds w3", float, 1024, 2, 32, 32, 1, 1, 8, 256, false, true, true, TW_LDS, 3, false),
+        VN("16x8x8 t4 reg w2 pf nt0", 0, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
+        VN("16x8x8 t4 reg w2 pf nt1", 1, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
+        VN("16x8x8 t4 reg w2 pf nt2", 2, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
+        VN("16x8x8 t4 reg w2 pf nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
+        VN("16x8x8 t4 lds w4 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VN("16x8x8 t4 lds w3 pf nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 3, true),
+        VN("16x8x8 t4 lds w4 nt0", 0, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VN("16x8x8 t2 lds w4 pf nt3", 3, float, 1024, 3, 16, 8, 8, 1, 2, 128, false, true, true, TW_LDS, 4, true),
+        VN("16x8x8 t1 reg w2 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_REG, 2, false),
+        VN("8x8x16 t4 reg w2 pf nt3", 3, float, 1024, 3, 8, 8, 16, 1, 4, 256, false, true, true, TW_REG, 2, true),
+        VN("8x16x8 t4 reg w2 pf nt3", 3, float, 1024, 3, 8, 16, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
+        VN("4x4x8x8 t2 reg w4 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_REG, 4, false),
+        VN("4x4x8x8 t4 lds w4 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
     };
 #elif GROUP == 2  // ---- config 3: 500k x 93 ----
     const long long batch = 500000, outer = 1, inner = 1;
     const int N = 93;
     std::vector<Variant> vs = {
-        V("31x3 t64 192 lds w3", float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        D("dma 31x3 t64 192 lds w3", float, 93, 2, 31, 3, 1, 1, 64, 192, TW_LDS, 3),
-        D("dma 31x3 t32 96 lds w3", float, 93, 2, 31, 3, 1, 1, 32, 96, TW_LDS, 3),
-        D("dma 31x3 t32 128 lds w3", float, 93, 2, 31, 3, 1, 1, 32, 128, TW_LDS, 3),
-        D("dma 31x3 t64 256 lds w3", float, 93, 2, 31, 3, 1, 1, 64, 256, TW_LDS, 3),
-        D("dma 31x3 t64 192 lds w2", float, 93, 2, 31, 3, 1, 1, 64, 192, TW_LDS, 2),
-        D("dma 31x3 t48 192 lds w3", float, 93, 2, 31, 3, 1, 1, 48, 192, TW_LDS, 3),
-        D("dma 31x3 t64 192 glb w3", float, 93, 2, 31, 3, 1, 1, 64, 192, TW_GLOBAL, 3),
-        D("dma 3x31 t64 192 lds w3", float, 93, 2, 3, 31, 1, 1, 64, 192, TW_LDS, 3),
+        VN("31x3 t64 192 lds w3 nt0", 0, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VN("31x3 t64 192 lds w3 nt3", 3, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VN("31x3 t64 192 lds w3 nt1", 1, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VN("31x3 t64 192 lds w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VN("31x3 t32 96 lds w3 nt3", 3, float, 93, 2, 31, 3, 1, 1, 32, 96, false, false, false, TW_LDS, 3, false),
     };
 #elif GROUP == 3  // ---- 500k x 128 rows (config 1 shape, config 5 z axis) ----
     const long long batch = 500000, outer = 1, inner = 1;
