@@ -172,6 +172,21 @@ def test_batch_range_and_untouched_rows():
     assert np.isnan(empty).all()
 
 
+@pytest.mark.parametrize("shape", [(10, 1024), (37, 93), (21, 128), (19, 480), (3, 40, 64)])
+def test_results_do_not_depend_on_the_tile_slot(shape):
+    """The same transform placed at every position of the batch gives bit-identical output (FMA placement is
+    pinned in fft_radix.h), so splitting the batch over tiles, slabs or GPUs cannot change a single bit."""
+    rng = np.random.default_rng(23)
+    one = rng.standard_normal((1,) + shape[1:] + (2,)).astype(np.float32)
+    x = np.repeat(one, shape[0], axis=0)
+    out, plan = gpu_fft(x, out_dtype=np.float32)
+    assert plan.kernel_name(len(shape) - 2) != "generic"
+    for i in range(1, shape[0]):
+        assert np.array_equal(out[i], out[0]), i
+    again, _ = gpu_fft(x, out_dtype=np.float32)
+    assert np.array_equal(again, out)
+
+
 def test_errors_from_the_device_side_of_the_boundary():
     x = torch.zeros((2, 8, 2), device=DEV)
     plan = mf.plan_fft(torch.float32, torch.float32, (2, 8, 2), (2, 8, 2))

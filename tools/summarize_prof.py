@@ -25,9 +25,15 @@ def short(name):
     return name[:60] + "..."
 
 
+def newest(pattern):
+    """gpurun merges every run into the same directory: keep only the most recent file of a pass"""
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def kernel_stats(d):
     rows = []
-    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+    for f in newest(os.path.join(d, "**", "*kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
             rows.append({"kernel": short(r["Name"]), "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                          "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
@@ -38,7 +44,7 @@ def kernel_stats(d):
 def pmc(d, counter):
     """average counter value per dispatch, per kernel"""
     acc = defaultdict(list)
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(d, "**", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == counter:
                 acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
