@@ -11,7 +11,8 @@ static const FastEntry kFastTable[] = {
     // ---- contiguous dimension, fp32 ----
     // 1024: LDS twiddles at 4 waves/SIMD.  (Register twiddles + prefetch measured the same 0.299 ms but sit on
     // the 256-VGPR edge: a refactor that added 20 B of scratch doubled their time.)
-    MIFFT_CFG_STREAM("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+    // streaming twin: four small-radix passes, 512 threads x 8 elements (low VGPR count, 32 waves/CU): 0.274 ms
+    MIFFT_CFG_STREAM("rows1024_4x4x8x8", float, MIFFT_F32, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
     MIFFT_CFG_CR("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
     MIFFT_CFG_CR("rows256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, false, true, true, TW_LDS, 2, false),
@@ -27,8 +28,8 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_CR("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_CR("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     // ---- strided dimensions, fp32 (in place, LDS column tiles) ----
-    MIFFT_CFG("cols640_4x4x8x5", float, MIFFT_F32, 640, 4, 4, 4, 8, 5, 16, 512, true, true, true, TW_LDS, 1, false),
-    MIFFT_CFG("cols480_4x4x6x5", float, MIFFT_F32, 480, 4, 4, 4, 6, 5, 16, 512, true, true, true, TW_LDS, 1, false),
+    MIFFT_CFG("cols640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+    MIFFT_CFG("cols480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
     MIFFT_CFG("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, true, TW_LDS, 2, false),

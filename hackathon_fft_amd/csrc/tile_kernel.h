@@ -172,6 +172,24 @@ MIFFT_DEV long long gaddr(const TileParams& p, long long base, int c, int n) {
         return base + (long long)c * C::N + n;
 }
 
+// Addressing split for HBM accesses: address = (uniform tile pointer + uniform element step) + 32-bit lane
+// offset.  The uniform part lives in SGPRs, each butterfly carries ONE offset VGPR for all of its R accesses
+// (global_load v, v_off, s[base] form) instead of R 64-bit address pairs.
+template <class C>
+MIFFT_DEV unsigned lane_off(const TileParams& p, int c, int n) {  // n: element index inside the transform
+    if constexpr (C::COLS)
+        return (unsigned)n * (unsigned)p.inner + (unsigned)c;
+    else
+        return (unsigned)c * (unsigned)C::N + (unsigned)n;
+}
+template <class C>
+MIFFT_DEV long long elem_stride(const TileParams& p) {
+    if constexpr (C::COLS)
+        return p.inner;
+    else
+        return 1;
+}
+
 template <class C, int I>
 MIFFT_DEV void item_decode(int id, int& c, int& b) {
     if constexpr (C::COLS) {
@@ -252,13 +270,15 @@ MIFFT_DEV void load_pass0(const TileParams& p, cpx<typename C::T> (*v)[C::R(0)],
             // transform (always in bounds; its results are never stored).  Branch-free loads stay back to back
             // with a single wait at first use -- per-load exec-masked blocks cost 40 % on the column tiles.
             const int cc = c < nv ? c : nv - 1;
+            const unsigned off = lane_off<C>(p, cc, b);
+            const long long step = (long long)NB * elem_stride<C>(p);  // uniform: element j sits j*step further
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 if constexpr (C::IN_REAL) {
-                    v[k][j].x = gload_real<(C::NT & 1) != 0>((const T*)p.in + gaddr<C>(p, base, cc, b + j * NB));
+                    v[k][j].x = gload_real<(C::NT & 1) != 0>((const T*)p.in + base + j * step + off);
                     v[k][j].y = (T)0;
                 } else {
-                    v[k][j] = gload<(C::NT & 1) != 0>(gin + gaddr<C>(p, base, cc, b + j * NB));
+                    v[k][j] = gload<(C::NT & 1) != 0>(gin + base + j * step + off);
                 }
             }
         }
@@ -332,6 +352,8 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
             const int o0 = q * P * R + pp;
             if constexpr (DST_GLOBAL) {
                 if (c < nv) {
+                    const unsigned off = lane_off<C>(p, c, o0);
+                    const long long step = (long long)P * elem_stride<C>(p);  // uniform
 #pragma unroll
                     for (int s = 0; s < R; ++s) {
                         V y = v[k][s];
@@ -339,7 +361,7 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
                             y.x *= (T)p.scale;
                             y.y *= -(T)p.scale;
                         }
-                        gstore<(C::NT & 2) != 0>(gout + gaddr<C>(p, base, c, o0 + s * P), y);
+                        gstore<(C::NT & 2) != 0>(gout + base + s * step + off, y);
                     }
                 }
             } else {

@@ -182,19 +182,19 @@ int main(int argc, char** argv) {
     const long long batch = 100, outer = 1, inner = 480;
     const int N = 640;
     std::vector<Variant> vs = {
-        V("c640 4x4x5x8 t16 512 lds", float, 640, 4, 4, 4, 5, 8, 16, 512, true, true, true, TW_LDS, 1, false),
-        V("c640 4x4x5x8 t16 512 glb w4", float, 640, 4, 4, 4, 5, 8, 16, 512, true, true, true, TW_GLOBAL, 4, false),
-        V("c640 4x4x5x8 t16 512 glb w2", float, 640, 4, 4, 4, 5, 8, 16, 512, true, true, true, TW_GLOBAL, 2, false),
-        V("c640 4x4x5x8 t16 256 glb w2", float, 640, 4, 4, 4, 5, 8, 16, 256, true, true, true, TW_GLOBAL, 2, false),
-        V("c640 4x4x5x8 t16 512 reg w4", float, 640, 4, 4, 4, 5, 8, 16, 512, true, true, true, TW_REG, 4, false),
-        V("c640 4x4x5x8 t16 1024 lds", float, 640, 4, 4, 4, 5, 8, 16, 1024, true, true, true, TW_LDS, 1, false),
-        V("c640 5x4x4x8 t16 512 lds", float, 640, 4, 5, 4, 4, 8, 16, 512, true, true, true, TW_LDS, 1, false),
-        V("c640 8x5x4x4 t16 512 lds", float, 640, 4, 8, 5, 4, 4, 16, 512, true, true, true, TW_LDS, 1, false),
-        V("c640 4x5x4x8 t16 512 lds", float, 640, 4, 4, 5, 4, 8, 16, 512, true, true, true, TW_LDS, 1, false),
-        V("c640 4x4x4x10 t16 512 lds", float, 640, 4, 4, 4, 4, 10, 16, 512, true, true, true, TW_LDS, 1, false),
         V("c640 4x4x8x5 t16 512 lds", float, 640, 4, 4, 4, 8, 5, 16, 512, true, true, true, TW_LDS, 1, false),
-        V("c640 4x4x5x8 t8 256 lds w2", float, 640, 4, 4, 4, 5, 8, 8, 256, true, true, true, TW_LDS, 2, false),
-        V("c640 4x4x5x8 t12 384 lds", float, 640, 4, 4, 4, 5, 8, 12, 384, true, true, true, TW_LDS, 2, false),
+        V("c640 4x4x8x5 t16 512 lds pf", float, 640, 4, 4, 4, 8, 5, 16, 512, true, true, true, TW_LDS, 1, true),
+        V("c640 4x4x8x5 t16 1024 lds", float, 640, 4, 4, 4, 8, 5, 16, 1024, true, true, true, TW_LDS, 1, false),
+        V("c640 4x4x8x5 t16 1024 lds pf", float, 640, 4, 4, 4, 8, 5, 16, 1024, true, true, true, TW_LDS, 1, true),
+        V("c640 4x4x8x5 t8 256 lds w2", float, 640, 4, 4, 4, 8, 5, 8, 256, true, true, true, TW_LDS, 2, false),
+        V("c640 4x4x8x5 t8 256 lds w2 pf", float, 640, 4, 4, 4, 8, 5, 8, 256, true, true, true, TW_LDS, 2, true),
+        V("c640 4x4x8x5 t8 512 lds w2", float, 640, 4, 4, 4, 8, 5, 8, 512, true, true, true, TW_LDS, 2, false),
+        V("c640 4x4x8x5 t8 512 lds w2 pf", float, 640, 4, 4, 4, 8, 5, 8, 512, true, true, true, TW_LDS, 2, true),
+        V("c640 10x8x8 t16 512 lds", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 10x8x8 t16 512 lds pf", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        V("c640 8x8x10 t16 512 lds", float, 640, 3, 8, 8, 10, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 4x4x8x5 t16 768 lds", float, 640, 4, 4, 4, 8, 5, 16, 768, true, true, true, TW_LDS, 1, false),
+        V("c640 4x4x8x5 t16 640 lds", float, 640, 4, 4, 4, 8, 5, 16, 640, true, true, true, TW_LDS, 1, false),
     };
 #elif GROUP == 5  // ---- config 4 first pass: 64000 rows of 480 ----
     const long long batch = 64000, outer = 1, inner = 1;
