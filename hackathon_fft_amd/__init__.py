@@ -6,6 +6,7 @@ from .api import (  # noqa: F401
     DeviceContext,
     GPUTest,
     Plan,
+    clear_plan_cache,
     estimate_best_bases,
     estimate_best_bases_nd,
     fft,
@@ -18,6 +19,6 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "DeviceContext", "GPUTest", "Plan", "MifftError", "estimate_best_bases", "estimate_best_bases_nd",
+    "DeviceContext", "GPUTest", "Plan", "clear_plan_cache", "MifftError", "estimate_best_bases", "estimate_best_bases_nd",
     "fft", "fftn", "ifftn", "ordered_bases", "plan_fft", "rfftn", "time_fft",
 ]

@@ -13,6 +13,7 @@ an FFT on the host or through torch.fft.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import enum
 from typing import Optional, Sequence
@@ -240,19 +241,46 @@ def _as_interleaved(x: "torch.Tensor"):
     return x.contiguous(), False
 
 
+_PLAN_CACHE: "collections.OrderedDict" = collections.OrderedDict()
+_PLAN_CACHE_SIZE = 32
+
+
+def _cached_plan(in_dtype, out_dtype, in_shape, out_shape, radices, inverse, faithful_stages, device) -> Plan:
+    """Plans of the convenience wrappers are kept (LRU): a plan is a few small device tables, building one
+    costs a hipMalloc + copy per dimension, and its tables must outlive the kernels enqueued with it."""
+    key = (in_dtype, out_dtype, in_shape, out_shape,
+           None if radices is None else tuple(tuple(int(b) for b in r) for r in radices),
+           bool(inverse), bool(faithful_stages), device)
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        plan = plan_fft(in_dtype, out_dtype, in_shape, out_shape, bases=radices, inverse=inverse,
+                        faithful_stages=faithful_stages, ctx=DeviceContext(device))
+        _PLAN_CACHE[key] = plan
+        while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+            _, old = _PLAN_CACHE.popitem(last=False)
+            torch.cuda.synchronize(old.device)  # nothing enqueued with the evicted plan may still run
+            old.close()
+    else:
+        _PLAN_CACHE.move_to_end(key)
+    return plan
+
+
+def clear_plan_cache() -> None:
+    for plan in _PLAN_CACHE.values():
+        torch.cuda.synchronize(plan.device)
+        plan.close()
+    _PLAN_CACHE.clear()
+
+
 def _run(x: "torch.Tensor", *, radices, inverse: bool, out_dtype, faithful_stages: bool) -> "torch.Tensor":
     xr, was_complex = _as_interleaved(x)
     if out_dtype is None:
         out_dtype = xr.dtype if xr.dtype in (torch.float32, torch.float64) else torch.float64
     out_shape = tuple(xr.shape[:-1]) + (2,)
-    ctx = DeviceContext(xr.device.index)
-    plan = plan_fft(xr.dtype, out_dtype, tuple(xr.shape), out_shape, bases=radices, inverse=inverse,
-                    faithful_stages=faithful_stages, ctx=ctx)
+    plan = _cached_plan(xr.dtype, out_dtype, tuple(xr.shape), out_shape, radices, inverse, faithful_stages,
+                        xr.device.index)
     out = torch.empty(out_shape, dtype=out_dtype, device=xr.device)
-    fft(out, xr, ctx, plan=plan)
-    # the plan's tables must outlive the enqueued kernels
-    ctx.synchronize()
-    plan.close()
+    fft(out, xr, DeviceContext(xr.device.index), plan=plan)  # asynchronous on the current stream, like torch ops
     return torch.view_as_complex(out) if was_complex else out
 
 

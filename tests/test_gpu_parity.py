@@ -211,6 +211,17 @@ def test_convenience_wrappers():
     xr = torch.from_numpy(rng.standard_normal((2, 30))).to(DEV)
     full = mf.rfftn(xr)
     np.testing.assert_allclose(to_complex(full.cpu().numpy()), np.fft.fft(xr.cpu().numpy(), axis=1), atol=1e-12)
+    # wrappers are asynchronous on the current stream and reuse cached plans
+    from hackathon_fft_amd import api
+    before = len(api._PLAN_CACHE)
+    ys = [mf.fftn(xc, radices=[[4, 2], [3, 2]]) for _ in range(20)]
+    assert len(api._PLAN_CACHE) == before
+    assert all(torch.equal(ys[0], t) for t in ys[1:])
+    for n in range(2, 2 + api._PLAN_CACHE_SIZE + 5):   # eviction path
+        mf.fftn(torch.zeros((1, n), dtype=torch.complex64, device=DEV))
+    assert len(api._PLAN_CACHE) == api._PLAN_CACHE_SIZE
+    mf.clear_plan_cache()
+    assert len(api._PLAN_CACHE) == 0
 
 
 # ---- full BASELINE sizes: properties that need no CPU reference ----------------------------
