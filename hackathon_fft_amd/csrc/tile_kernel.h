@@ -524,9 +524,13 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel_dma(const Til
     static_assert(C::DMA && !C::COLS && !C::FIRST_DIRECT && !C::LAST_DIRECT && !C::IN_REAL && C::LD == C::N,
                   "DMA staging is for the flat-copy row configurations");
     static_assert(C::TWMODE != TW_REG, "register twiddles not wired for the DMA variant");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    V* lds = (V*)smem;
-    V* stage = lds + C::STAGE_OFF;
+    // Two DISTINCT LDS objects: the module-LDS lowering gives each its own alias scope, which lets the
+    // waitcnt pass see that LDS writes into the work buffer do not touch the DMA destination -- with one
+    // (dynamic) LDS array it put s_waitcnt vmcnt(0) in front of the first ds_write after the DMA issue.
+    __shared__ __attribute__((aligned(16))) V s_work[C::DATA_ELEMS + (C::TWL_TOTAL > 0 ? C::TWL_TOTAL : 1)];
+    __shared__ __attribute__((aligned(16))) V s_stage[C::STAGE_ELEMS];
+    V* lds = s_work;
+    V* stage = s_stage;
     const int tid = threadIdx.x;
     V twr[1];
     if constexpr (C::TWMODE == TW_LDS) fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, tid, p.inverse);

@@ -85,13 +85,8 @@ Variant make_dma(const char* name) {
         tp.tiles_per_outer = 1;
         tp.n_tiles = (tp.n_rows + C::TILE - 1) / C::TILE;
         auto k = tile_kernel_dma<C>;
-        static bool set = false;
-        if (!set && C::LDS_BYTES > 64 * 1024) {
-            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-            set = true;
-        }
         long long grid = tile_grid<C>(g_cus, tp.n_tiles, g_wg_override);
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), C::LDS_BYTES, 0, tp);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), 0, 0, tp);  // static LDS
     };
     return v;
 }
@@ -127,8 +122,8 @@ Variant make_plane(const char* name) {
 // explicit non-temporal mode: ... PF, then NT (0 none, 1 loads, 2 stores, 3 both)
 #define VN(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, false, false, NT>>(NAME)
 // DMA-staged flat-copy rows: T N NP R0..R3 TILE THREADS TWMODE MINW
-#define D(NAME, T, N, NP, R0, R1, R2, R3, TILE, THR, TWM, MINW) \
-    make_dma<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THR, false, false, false, TWM, MINW, false, 0, false, true>>(NAME)
+#define D(NAME, NTM, T, N, NP, R0, R1, R2, R3, TILE, THR, TWM, MINW) \
+    make_dma<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THR, false, false, false, TWM, MINW, false, 0, false, true, NTM>>(NAME)
 #define PL(NAME, THR, MINW, PF, R0, R1, R2, R3, NP)                                                              \
     make_plane<TileCfg<float, 128, NP, R0, R1, R2, R3, 128, THR, false, true, false, TW_LDS, MINW, PF>,          \
                TileCfg<float, 128, NP, R0, R1, R2, R3, 128, THR, true, false, true, TW_LDS, MINW, false>>(NAME)
@@ -162,10 +157,14 @@ int main(int argc, char** argv) {
     const int N = 93;
     std::vector<Variant> vs = {
         VN("31x3 t64 192 lds w3 nt0", 0, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VN("31x3 t64 192 lds w3 nt3", 3, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VN("31x3 t64 192 lds w3 nt1", 1, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
         VN("31x3 t64 192 lds w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VN("31x3 t32 96 lds w3 nt3", 3, float, 93, 2, 31, 3, 1, 1, 32, 96, false, false, false, TW_LDS, 3, false),
+        D("dma 31x3 t64 192 w3 nt0", 0, float, 93, 2, 31, 3, 1, 1, 64, 192, TW_LDS, 3),
+        D("dma 31x3 t64 192 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, TW_LDS, 3),
+        D("dma 31x3 t32 96 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 32, 96, TW_LDS, 3),
+        D("dma 31x3 t32 128 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 32, 128, TW_LDS, 3),
+        D("dma 31x3 t48 192 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 48, 192, TW_LDS, 3),
+        D("dma 31x3 t40 128 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 40, 128, TW_LDS, 3),
+        D("dma 31x3 t22 64 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 22, 64, TW_LDS, 3),
     };
 #elif GROUP == 3  // ---- 500k x 128 rows (config 1 shape, config 5 z axis) ----
     const long long batch = 500000, outer = 1, inner = 1;
