@@ -207,6 +207,9 @@ struct DftOddPrime {
         }
     }
     static MIFFT_DEV void run(cpx<T>* v) {
+#ifdef MIFFT_ABLATE_PRIME_DFT  // timing experiment only: how fast is the kernel around a free butterfly?
+        if (R > 16) return;
+#endif
         cpx<T> a[H], b[H];
 #pragma unroll
         for (int j = 1; j <= H; ++j) {
@@ -218,6 +221,42 @@ struct DftOddPrime {
         for (int j = 0; j < H; ++j) sum = sum + a[j];
         v[0] = sum;
         outputs<1>(v, x0, a, b);
+    }
+};
+
+// ---- odd prime R, OUTPUT-SPLIT form: lane group g of G computes only the conjugate pairs
+//      s in [g*PP + 1, (g+1)*PP] (PP = ceil(H / G)) -- group 0 also X_0 -- and hands every result to
+//      `emit(s, value)` at once, so nothing but the a/b sums stays live.  Used where the butterfly count
+//      per row is tiny (93 = 31 * 3 has three) to put G lanes on one butterfly. ----
+template <int R, typename T, int G, int g>
+struct PrimeGroup {
+    static constexpr int H = (R - 1) / 2, PP = (H + G - 1) / G, S0 = g * PP + 1,
+                         S1 = (S0 + PP - 1 < H) ? (S0 + PP - 1) : H;
+    template <int s, class Emit>
+    static MIFFT_DEV void pairs(cpx<T> x0, const cpx<T>* a, const cpx<T>* b, Emit& emit) {
+        if constexpr (s <= S1) {
+            cpx<T> A = x0, B = {(T)0, (T)0};
+            DftOddPrime<R, T, 1>::template acc<s, 1>(a, b, A, B);
+            emit(s, cpx<T>{A.x + B.y, A.y - B.x});
+            emit(R - s, cpx<T>{A.x - B.y, A.y + B.x});
+            pairs<s + 1>(x0, a, b, emit);
+        }
+    }
+    template <class Emit>
+    static MIFFT_DEV void run(const cpx<T>* x, Emit& emit) {
+        cpx<T> a[H], b[H];
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            a[j - 1] = x[j] + x[R - j];
+            b[j - 1] = x[j] - x[R - j];
+        }
+        if constexpr (g == 0) {
+            cpx<T> sum = x[0];
+#pragma unroll
+            for (int j = 0; j < H; ++j) sum = sum + a[j];
+            emit(0, sum);
+        }
+        pairs<S0>(x[0], a, b, emit);
     }
 };
 

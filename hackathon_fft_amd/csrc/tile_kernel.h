@@ -585,6 +585,102 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel_dma(const Til
 }
 
 // ---------------------------------------------------------------------------------------------
+// tile_kernel_dma_split<C, G>: tile_kernel_dma with an OUTPUT-SPLIT prime pass 0.  A row of 93 = 31 * 3
+// points has only three 31-point butterflies, each ~170 live VGPRs: too few, too fat work items to hide
+// their latency (with a free butterfly the DMA kernel reaches 0.131 ms at 500k x 93, with the real one
+// 0.167 ms).  Here G lanes share one butterfly: lane group g reads the 31 staged inputs, forms the
+// conjugate sums and computes only its own output pairs, writing each to the work buffer at once.
+// Slots are laid out [g][padded item] with the pad a multiple of 64, so g is wave-uniform and its
+// constants stay compile-time.
+// ---------------------------------------------------------------------------------------------
+template <class C, int G, int g0, class X, class Emit>
+MIFFT_DEV void prime_group_dispatch(int g, const X* x, Emit& emit) {
+    if constexpr (g0 < G) {
+        if (g == g0)
+            PrimeGroup<C::R(0), typename C::T, G, g0>::run(x, emit);
+        else
+            prime_group_dispatch<C, G, g0 + 1>(g, x, emit);
+    }
+}
+
+template <class C, int G>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel_dma_split(const TileParams p) {
+    using T = typename C::T;
+    using V = cpx<T>;
+    static_assert(C::DMA && !C::COLS && !C::FIRST_DIRECT && !C::LAST_DIRECT && !C::IN_REAL && C::LD == C::N,
+                  "DMA staging is for the flat-copy row configurations");
+    static_assert(C::TWMODE != TW_REG && is_prime_ce(C::R(0)) && C::R(0) > 2 && C::THREADS % 64 == 0, "split prime pass 0");
+    __shared__ __attribute__((aligned(16))) V s_work[C::DATA_ELEMS + (C::TWL_TOTAL > 0 ? C::TWL_TOTAL : 1)];
+    __shared__ __attribute__((aligned(16))) V s_stage[C::STAGE_ELEMS];
+    V* lds = s_work;
+    V* stage = s_stage;
+    const int tid = threadIdx.x;
+    V twr[1];
+    if constexpr (C::TWMODE == TW_LDS) fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, tid, p.inverse);
+
+    constexpr int R0 = C::R(0), NB0 = C::NB(0);
+    constexpr int PER_G = NB0 * C::TILE, PAD = (PER_G + 63) / 64 * 64, SLOTS = PAD * G;
+    constexpr int ROUNDS = (SLOTS + C::THREADS - 1) / C::THREADS;
+
+    long long t = blockIdx.x;
+    if (t < p.n_tiles) {
+        long long base;
+        int nv;
+        tile_geom<C>(p, t, base, nv);
+        dma_issue_tile<C>(p, stage, base, nv, tid);
+    }
+    for (; t < p.n_tiles; t += gridDim.x) {
+        long long base;
+        int nv;
+        tile_geom<C>(p, t, base, nv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg_barrier<C>();
+        // ---- pass 0: staged rows -> G lanes per prime butterfly -> work buffer ----
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int id = tid + k * C::THREADS;
+            if (SLOTS % C::THREADS == 0 || id < SLOTS) {
+                const int g = __builtin_amdgcn_readfirstlane(id / PAD);  // PAD and THREADS are multiples of 64
+                const int r = id - g * PAD;
+                if (r < PER_G) {
+                    const int c = r / NB0, b = r - c * NB0;
+                    V x[R0];
+#pragma unroll
+                    for (int j = 0; j < R0; ++j) x[j] = stage[c * C::N + b + j * NB0];
+                    if (p.inverse) {
+#pragma unroll
+                        for (int j = 0; j < R0; ++j) x[j].y = -x[j].y;
+                    }
+                    V* row = lds + c * C::LD;
+                    auto emit = [&](int s, V val) { row[swz<C, 0>(b * R0 + s)] = val; };  // P = 1: position q*R + s
+                    prime_group_dispatch<C, G, 0>(g, x, emit);
+                }
+            }
+        }
+        wg_barrier<C>();  // staging buffer consumed, work buffer holds pass-0 output
+        const long long tn = t + gridDim.x;
+        if (tn < p.n_tiles) {
+            long long nbase;
+            int nnv;
+            tile_geom<C>(p, tn, nbase, nnv);
+            dma_issue_tile<C>(p, stage, nbase, nnv, tid);
+        }
+        V none[1][R0];
+        run_pass<C, 1>(p, lds, twr, none, base, nv, tid);
+        V* gout = (V*)p.out;
+        const int total = nv * C::N;
+        for (int f = tid; f < total; f += C::THREADS) {
+            V y = lds[f];
+            if (p.inverse) {
+                y.x *= (T)p.scale;
+                y.y *= -(T)p.scale;
+            }
+            gstore<(C::NT & 2) != 0>(gout + base + f, y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // plane_kernel<CR, CC>: the two innermost dimensions (N1 x N2, N2 contiguous) of one 2-D slice are
 // transformed inside ONE LDS tile: the rows (length N2) by the ROWS configuration CR -- pass 0 straight
 // from HBM, last pass left in LDS in natural order -- then the columns (length N1, LDS stride N2) by

@@ -91,6 +91,29 @@ Variant make_dma(const char* name) {
     return v;
 }
 
+template <class C, int G>
+Variant make_dma_split(const char* name) {
+    Variant v;
+    v.name = name;
+    v.lds = C::LDS_BYTES;
+    v.run = [](const void* in, void* out, const void* tw, long long batch, long long outer, long long inner) {
+        TileParams tp{};
+        tp.in = in;
+        tp.out = out;
+        tp.tw = tw;
+        tp.inverse = 0;
+        tp.scale = 1.0;
+        tp.n_rows = batch * outer;
+        tp.inner = 1;
+        tp.tiles_per_outer = 1;
+        tp.n_tiles = (tp.n_rows + C::TILE - 1) / C::TILE;
+        auto k = tile_kernel_dma_split<C, G>;
+        long long grid = tile_grid<C>(g_cus, tp.n_tiles, g_wg_override);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), 0, 0, tp);
+    };
+    return v;
+}
+
 template <class CR, class CC>
 Variant make_plane(const char* name) {
     Variant v;
@@ -122,6 +145,8 @@ Variant make_plane(const char* name) {
 // explicit non-temporal mode: ... PF, then NT (0 none, 1 loads, 2 stores, 3 both)
 #define VN(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, false, false, NT>>(NAME)
 // DMA-staged flat-copy rows: T N NP R0..R3 TILE THREADS TWMODE MINW
+#define DS(NAME, G, NTM, T, N, NP, R0, R1, R2, R3, TILE, THR, TWM, MINW) \
+    make_dma_split<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THR, false, false, false, TWM, MINW, false, 0, false, true, NTM>, G>(NAME)
 #define D(NAME, NTM, T, N, NP, R0, R1, R2, R3, TILE, THR, TWM, MINW) \
     make_dma<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THR, false, false, false, TWM, MINW, false, 0, false, true, NTM>>(NAME)
 #define PL(NAME, THR, MINW, PF, R0, R1, R2, R3, NP)                                                              \
@@ -156,15 +181,19 @@ int main(int argc, char** argv) {
     const long long batch = 500000, outer = 1, inner = 1;
     const int N = 93;
     std::vector<Variant> vs = {
-        VN("31x3 t64 192 lds w3 nt0", 0, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
         VN("31x3 t64 192 lds w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        D("dma 31x3 t64 192 w3 nt0", 0, float, 93, 2, 31, 3, 1, 1, 64, 192, TW_LDS, 3),
-        D("dma 31x3 t64 192 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, TW_LDS, 3),
-        D("dma 31x3 t32 96 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 32, 96, TW_LDS, 3),
-        D("dma 31x3 t32 128 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 32, 128, TW_LDS, 3),
         D("dma 31x3 t48 192 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 48, 192, TW_LDS, 3),
-        D("dma 31x3 t40 128 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 40, 128, TW_LDS, 3),
-        D("dma 31x3 t22 64 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 22, 64, TW_LDS, 3),
+        DS("split5 t32 640 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 32, 640, TW_LDS, 1),
+        DS("split5 t32 320 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 32, 320, TW_LDS, 1),
+        DS("split5 t32 256 w2 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 32, 256, TW_LDS, 2),
+        DS("split3 t32 384 w1 nt2", 3, 2, float, 93, 2, 31, 3, 1, 1, 32, 384, TW_LDS, 1),
+        DS("split3 t32 192 w2 nt2", 3, 2, float, 93, 2, 31, 3, 1, 1, 32, 192, TW_LDS, 2),
+        DS("split5 t64 960 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 64, 960, TW_LDS, 1),
+        DS("split5 t64 512 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 64, 512, TW_LDS, 1),
+        DS("split5 t42 640 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 42, 640, TW_LDS, 1),
+        DS("split8 t32 1024 w1 nt2", 8, 2, float, 93, 2, 31, 3, 1, 1, 32, 1024, TW_LDS, 1),
+        DS("split5 t32 640 w1 nt0", 5, 0, float, 93, 2, 31, 3, 1, 1, 32, 640, TW_LDS, 1),
+        DS("split5 t20 384 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 20, 384, TW_LDS, 1),
     };
 #elif GROUP == 3  // ---- 500k x 128 rows (config 1 shape, config 5 z axis) ----
     const long long batch = 500000, outer = 1, inner = 1;
