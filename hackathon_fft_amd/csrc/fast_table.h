@@ -28,12 +28,6 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
         tp.n_tiles = (tp.n_rows + C::TILE - 1) / C::TILE;
     }
     auto k = tile_kernel<C>;
-    static bool attr_set = false;
-    if (C::LDS_BYTES > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute");
-        attr_set = true;
-    }
     const long long grid = tile_grid<C>(plan.num_cus, tp.n_tiles);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), C::LDS_BYTES, stream, tp);
     hipError_t e = hipGetLastError();
@@ -44,6 +38,18 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
 // ---------------------------------------------------------------------------------------------
 // configuration table.  NP, R0..R3, TILE, THREADS, COLS, FIRST_DIRECT, LAST_DIRECT, TWMODE, MINW, PREFETCH
 // ---------------------------------------------------------------------------------------------
+// plan-time preparation on the plan's (current) device: kernels whose tile needs more than 64 KiB of dynamic LDS
+// must opt in per device.  Done here, not in exec, so that exec contains nothing but launches (graph capture).
+template <class C>
+static int prepare_tile() {
+    if (C::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)tile_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)C::LDS_BYTES);
+        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    return MIFFT_OK;
+}
+
 struct FastEntry {
     bool in_real;     // the kernel promotes a real (C_in = 1) tensor in its pass-0 load
     int stream_pref;  // 1: only for streaming-size problems (non-temporal twin), -1: any size
@@ -52,6 +58,7 @@ struct FastEntry {
     bool cols;
     const char* name;
     LaunchFn launch;
+    int (*prepare)();
     int tile, threads;
     size_t lds;
 };
@@ -59,6 +66,7 @@ struct FastEntry {
 #define MIFFT_CFG_X(REAL, NTM, STREAM, NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                         \
     {                                                                                                               \
         REAL, STREAM, DT, N, COLS, NAME, launch_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM>>,   \
+            prepare_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM>>, \
             TILE, THREADS, TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM>::LDS_BYTES       \
     }
 

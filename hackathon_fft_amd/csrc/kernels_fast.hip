@@ -65,16 +65,20 @@ static int launch_plane(const Plan& plan, const DimPass& pass, const void* in, v
     tp.n_rows = 0;
     tp.n_tiles = count * pass.outer;  // planes
     auto k = plane_kernel<CR, CC>;
-    static bool attr_set = false;
-    if (CR::LDS_BYTES > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR::LDS_BYTES);
-        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute");
-        attr_set = true;
-    }
     const long long grid = tile_grid<CR>(plan.num_cus, tp.n_tiles);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(CR::THREADS), CR::LDS_BYTES, stream, tp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_error(e, "plane_kernel launch");
+    return MIFFT_OK;
+}
+
+template <class CR, class CC>
+static int prepare_plane() {
+    if (CR::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)plane_kernel<CR, CC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)CR::LDS_BYTES);
+        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
     return MIFFT_OK;
 }
 
@@ -83,6 +87,7 @@ struct PlaneEntry {
     int N1, N2;
     const char* name;
     LaunchFn launch;
+    int (*prepare)();
     int threads;
     size_t lds;
 };
@@ -95,7 +100,8 @@ using Plane64R = TileCfg<float, 64, 3, 4, 4, 4, 1, 64, 512, false, true, false, 
 using Plane64C = TileCfg<float, 64, 3, 4, 4, 4, 1, 64, 512, true, false, true, TW_LDS, 2, false>;
 
 static const PlaneEntry kPlaneTable[] = {
-    {MIFFT_F32, 64, 64, "plane64x64_4x4x4", launch_plane<Plane64R, Plane64C>, 512, Plane64R::LDS_BYTES},
+    {MIFFT_F32, 64, 64, "plane64x64_4x4x4", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>, 512,
+     Plane64R::LDS_BYTES},
 };
 
 bool select_fast_plane(const Plan& plan, DimPass& pass) {
@@ -104,6 +110,7 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
         if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
         pass.kernel_name = e.name;
         pass.launch = e.launch;
+        pass.prepare = e.prepare;
         pass.tile = 1;
         pass.threads = e.threads;
         pass.lds_bytes = e.lds;
@@ -127,6 +134,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         if (cols && pass.inner < e.tile) return false;
         pass.kernel_name = e.name;
         pass.launch = e.launch;
+        pass.prepare = e.prepare;
         pass.tile = e.tile;
         pass.threads = e.threads;
         pass.lds_bytes = e.lds;

@@ -169,12 +169,16 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericParams p) {
     }
 }
 
+// PREPARE = true: plan time, on the plan's device -- opt the instantiation in to > 64 KiB of dynamic LDS
+// (per device) instead of launching, so that exec contains nothing but launches.
 template <typename T, typename TIn, int COMPS, bool ROWS>
-static hipError_t launch_one(const GenericParams& gp, int grid, int threads, size_t lds, hipStream_t stream) {
+static hipError_t launch_one(const GenericParams& gp, int grid, int threads, size_t lds, hipStream_t stream,
+                             bool prepare = false) {
     auto k = generic_kernel<T, TIn, COMPS, ROWS>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+    if (prepare) {
+        if (lds > 64 * 1024)
+            return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return hipSuccess;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, stream, gp);
     return hipGetLastError();
@@ -182,23 +186,38 @@ static hipError_t launch_one(const GenericParams& gp, int grid, int threads, siz
 
 template <typename T>
 static hipError_t launch_first(const Plan& plan, const GenericParams& gp, int grid, int threads, size_t lds,
-                               hipStream_t s) {
+                               hipStream_t s, bool prep = false) {
     const int c = plan.in_components;
     switch (plan.in_dtype) {
         case MIFFT_F32:
-            return c == 1 ? launch_one<T, float, 1, true>(gp, grid, threads, lds, s)
-                          : launch_one<T, float, 2, true>(gp, grid, threads, lds, s);
+            return c == 1 ? launch_one<T, float, 1, true>(gp, grid, threads, lds, s, prep)
+                          : launch_one<T, float, 2, true>(gp, grid, threads, lds, s, prep);
         case MIFFT_F64:
-            return c == 1 ? launch_one<T, double, 1, true>(gp, grid, threads, lds, s)
-                          : launch_one<T, double, 2, true>(gp, grid, threads, lds, s);
+            return c == 1 ? launch_one<T, double, 1, true>(gp, grid, threads, lds, s, prep)
+                          : launch_one<T, double, 2, true>(gp, grid, threads, lds, s, prep);
         case MIFFT_U8:
-            return c == 1 ? launch_one<T, unsigned char, 1, true>(gp, grid, threads, lds, s)
-                          : launch_one<T, unsigned char, 2, true>(gp, grid, threads, lds, s);
+            return c == 1 ? launch_one<T, unsigned char, 1, true>(gp, grid, threads, lds, s, prep)
+                          : launch_one<T, unsigned char, 2, true>(gp, grid, threads, lds, s, prep);
         case MIFFT_I32:
-            return c == 1 ? launch_one<T, int, 1, true>(gp, grid, threads, lds, s)
-                          : launch_one<T, int, 2, true>(gp, grid, threads, lds, s);
+            return c == 1 ? launch_one<T, int, 1, true>(gp, grid, threads, lds, s, prep)
+                          : launch_one<T, int, 2, true>(gp, grid, threads, lds, s, prep);
     }
     return hipErrorInvalidValue;
+}
+
+// dispatch shared by exec (prep = false) and plan-time preparation (prep = true)
+static hipError_t dispatch_generic(const Plan& plan, const DimPass& pass, const GenericParams& gp, int grid,
+                                   hipStream_t stream, bool prep) {
+    const bool rows = pass.inner == 1;
+    const bool f32 = plan.out_dtype == MIFFT_F32;
+    if (pass.first)
+        return f32 ? launch_first<float>(plan, gp, grid, pass.threads, pass.lds_bytes, stream, prep)
+                   : launch_first<double>(plan, gp, grid, pass.threads, pass.lds_bytes, stream, prep);
+    if (rows)
+        return f32 ? launch_one<float, float, 2, true>(gp, grid, pass.threads, pass.lds_bytes, stream, prep)
+                   : launch_one<double, double, 2, true>(gp, grid, pass.threads, pass.lds_bytes, stream, prep);
+    return f32 ? launch_one<float, float, 2, false>(gp, grid, pass.threads, pass.lds_bytes, stream, prep)
+               : launch_one<double, double, 2, false>(gp, grid, pass.threads, pass.lds_bytes, stream, prep);
 }
 
 static int launch_generic(const Plan& plan, const DimPass& pass, const void* in, void* out, int64_t count,
@@ -231,18 +250,7 @@ static int launch_generic(const Plan& plan, const DimPass& pass, const void* in,
     }
     long long max_grid = (long long)plan.num_cus * 16;
     int grid = (int)(gp.n_tiles < max_grid ? gp.n_tiles : max_grid);
-    hipError_t e;
-    const bool f32 = plan.out_dtype == MIFFT_F32;
-    if (pass.first) {
-        e = f32 ? launch_first<float>(plan, gp, grid, pass.threads, pass.lds_bytes, stream)
-                : launch_first<double>(plan, gp, grid, pass.threads, pass.lds_bytes, stream);
-    } else if (rows) {
-        e = f32 ? launch_one<float, float, 2, true>(gp, grid, pass.threads, pass.lds_bytes, stream)
-                : launch_one<double, double, 2, true>(gp, grid, pass.threads, pass.lds_bytes, stream);
-    } else {
-        e = f32 ? launch_one<float, float, 2, false>(gp, grid, pass.threads, pass.lds_bytes, stream)
-                : launch_one<double, double, 2, false>(gp, grid, pass.threads, pass.lds_bytes, stream);
-    }
+    hipError_t e = dispatch_generic(plan, pass, gp, grid, stream, /*prep=*/false);
     if (e != hipSuccess) return hip_error(e, "generic_kernel launch");
     return MIFFT_OK;
 }
@@ -278,6 +286,14 @@ bool select_generic(const Plan& plan, DimPass& pass, std::string& why_not) {
     pass.lds_bytes = (size_t)(2 * tile * ld) * esz;
     pass.kernel_name = "generic";
     pass.launch = launch_generic;
+    if (pass.lds_bytes > 64 * 1024) {  // plan creation runs on the plan's device
+        GenericParams none{};
+        hipError_t e = dispatch_generic(plan, pass, none, 1, nullptr, /*prep=*/true);
+        if (e != hipSuccess) {
+            why_not = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e);
+            return false;
+        }
+    }
     return true;
 }
 

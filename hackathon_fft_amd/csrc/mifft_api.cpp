@@ -253,6 +253,14 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                 return set_error(MIFFT_ERR_TOO_LARGE, why);
             }
         }
+        if (ps.prepare) {
+            int prc = ps.prepare();
+            if (prc) {
+                free_plan_device(p);
+                delete h;
+                return prc;
+            }
+        }
         e = upload_twiddles(ps);
         p.passes.push_back(ps);
         if (e != hipSuccess) {

@@ -53,6 +53,7 @@ struct DimPass {
     void* d_aux = nullptr;            // kernel-family specific device table (may be null)
     const char* kernel_name = "none";
     LaunchFn launch = nullptr;
+    int (*prepare)() = nullptr;  // plan-time, on the plan's device (per-device kernel attributes)
     // geometry chosen by the kernel family at plan time
     int tile = 1;          // transforms per workgroup tile
     int ld = 0;            // LDS leading dimension (complex elements)

@@ -88,3 +88,30 @@ def test_plan_lifecycle():
         plan.close()  # idempotent
     ref = torch.view_as_real(torch.fft.fft(torch.view_as_complex(x.double().contiguous()), dim=1))
     assert ((out.double() - ref).norm() / ref.norm()).item() < 1e-5
+
+
+@pytest.mark.parametrize("shape,kw", [((2000, 1024), dict(bases=[[2]])), ((8, 640, 480), {}), ((3, 16384), {}),
+                                      ((4, 7680), dict(faithful_stages=True))])
+def test_exec_is_capturable_into_a_hip_graph(shape, kw):
+    """exec enqueues kernels only (no allocation, no attribute call, no sync): it can be captured and replayed."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(shape + (2,), generator=g, device=DEV)
+    out = torch.zeros_like(x)
+    side = torch.cuda.Stream()
+    ctx = mf.DeviceContext(0, side)
+    plan = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, ctx=ctx, **kw)   # big-LDS kernels included
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        mf.fft(out, x, ctx, plan=plan)            # warm-up outside capture
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            mf.fft(out, x, mf.DeviceContext(0), plan=plan)   # current stream = capture stream
+    expected = out.clone()
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, expected)
+    axes = tuple(range(1, len(shape)))
+    truth = torch.view_as_real(torch.fft.fftn(torch.view_as_complex(x[:2].double().contiguous()), dim=axes))
+    assert ((out[:2].double() - truth).norm() / truth.norm()).item() < 1e-5
