@@ -84,5 +84,7 @@ struct FastEntry {
 // kept TU-local there so that the device pass never sees the host launcher pointers)
 const FastEntry* gen_rows_table(int* count);
 const FastEntry* gen_cols_table(int* count);
+const FastEntry* gen_rows_f64_table(int* count);
+const FastEntry* gen_cols_f64_table(int* count);
 
 }  // namespace mifft

@@ -144,7 +144,11 @@ bool select_fast(const Plan& plan, DimPass& pass) {
     for (const FastEntry& e : kFastTable)  // hand-tuned entries win
         if (try_entry(e)) return true;
     int ngen = 0;
-    const FastEntry* gen = cols ? gen_cols_table(&ngen) : gen_rows_table(&ngen);
+    const FastEntry* gen;
+    if (plan.out_dtype == MIFFT_F64)
+        gen = cols ? gen_cols_f64_table(&ngen) : gen_rows_f64_table(&ngen);
+    else
+        gen = cols ? gen_cols_table(&ngen) : gen_rows_table(&ngen);
     for (int i = 0; i < ngen; ++i)
         if (try_entry(gen[i])) return true;
     return false;

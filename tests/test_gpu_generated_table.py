@@ -22,7 +22,7 @@ def _run(x_np):
     x = torch.from_numpy(x_np).to("cuda:0")
     out = torch.full_like(x, float("nan"))
     ctx = mf.DeviceContext(0)
-    plan = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, ctx=ctx)
+    plan = mf.plan_fft(x.dtype, x.dtype, x.shape, x.shape, ctx=ctx)
     mf.fft(out, x, ctx, plan=plan)
     ctx.synchronize()
     return out.cpu().numpy(), plan
@@ -49,4 +49,24 @@ def test_cols(n):
     assert not np.isnan(out).any()
     truth = np.fft.fftn(to_complex(x), axes=(1, 2))
     assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32, plan.kernel_name(0)
+    assert plan.kernel_name(0) != "generic", n
+
+
+@pytest.mark.parametrize("n", _gen.SIZES_F64)
+def test_rows_f64(n):
+    rng = np.random.default_rng(n + 2)
+    x = rng.standard_normal((67 if n <= 512 else 5, n, 2))
+    out, plan = _run(x)
+    truth = np.fft.fft(to_complex(x), axis=1)
+    assert rel_l2(out, from_complex(truth, np.float64)) < 1e-12, plan.kernel_name(0)
+    assert plan.kernel_name(0) != "generic", n
+
+
+@pytest.mark.parametrize("n", [s for s in _gen.SIZES_F64 if s <= 2048])
+def test_cols_f64(n):
+    rng = np.random.default_rng(n + 3)
+    x = rng.standard_normal((2, n, 20, 2))     # 20 columns: ragged against the 8-column f64 tile
+    out, plan = _run(x)
+    truth = np.fft.fftn(to_complex(x), axes=(1, 2))
+    assert rel_l2(out, from_complex(truth, np.float64)) < 1e-12, plan.kernel_name(0)
     assert plan.kernel_name(0) != "generic", n

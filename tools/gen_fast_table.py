@@ -46,10 +46,10 @@ def factorizations(n, k, allowed):
     return res
 
 
-def choose(n, cols):
+def choose(n, cols, allowed=None):
     best = None
     for k in (2, 3, 4):
-        for f in factorizations(n, k, ALLOWED):
+        for f in factorizations(n, k, allowed or ALLOWED):
             mx = max(f)
             if cols:
                 # small radices first priority; 4 passes fine
@@ -71,50 +71,62 @@ def pow2ceil(v):
     return p
 
 
-def row_cfg(n):
-    f = choose(n, False)
+ALLOWED_F64 = [2, 3, 4, 5, 6, 7, 8, 9, 10]   # 16-byte elements: keep butterflies small
+
+
+def row_cfg(n, f64=False):
+    f = choose(n, False, ALLOWED_F64 if f64 else None)
     if f is None:
         return None
-    if n <= 4096:
-        tile = max(1, min(64, 4096 // n))
+    budget = 2048 if f64 else 4096          # elements per tile: 32 KiB of LDS either way
+    if n <= budget:
+        tile = max(1, min(64, budget // n))
         threads = 256
         # keep every pass busy: items of the largest-radix pass >= threads/2
         while tile * (n // max(f)) < threads // 2 and tile < 64:
             tile *= 2
     else:
-        if n > 8192:
+        if n > (4096 if f64 else 8192):
             return None  # 16 elements/thread needs 1024 threads = 128 VGPRs: spills
         tile = 1
-        threads = min(512, pow2ceil(n // 16))
+        threads = min(512, pow2ceil(n // (8 if f64 else 16)))
     fd = (n // f[0]) >= 16
     ld = (n // f[-1]) >= 16
     return f, tile, threads, fd, ld
 
 
-def col_cfg(n):
-    f = choose(n, True)
+def col_cfg(n, f64=False):
+    f = choose(n, True, ALLOWED_F64 if f64 else None)
     if f is None:
         return None
-    tile = 16
-    # <= 512 threads (256 VGPRs each) and <= 16 elements per thread (more spills); LDS <= 128 KiB
-    while (n * tile > 8192 or n * tile * 8 > 128 * 1024) and tile > 2:
+    tile = 8 if f64 else 16                 # 128-byte HBM runs
+    esz = 16 if f64 else 8
+    cap = 4096 if f64 else 8192             # <= 512 threads and <= 16 (8 for f64) elements per thread
+    while (n * tile > cap or n * tile * esz > 128 * 1024) and tile > 2:
         tile //= 2
-    if n * tile > 8192:
+    if n * tile > cap:
         return None
-    threads = max(128, min(512, pow2ceil((n * tile + 19) // 20)))
+    per = 10 if f64 else 20
+    threads = max(128, min(512, pow2ceil((n * tile + per - 1) // per)))
     return f, tile, threads
 
 
-def emit(name, n, f, tile, threads, cols, fd, ld):
+def emit(name, n, f, tile, threads, cols, fd, ld, f64=False):
     r = list(f) + [1] * (4 - len(f))
     rs = "x".join(str(v) for v in f)
-    return (f'    MIFFT_CFG("{name}{n}_{rs}", float, MIFFT_F32, {n}, {len(f)}, {r[0]}, {r[1]}, {r[2]}, {r[3]}, '
+    ty, dt, suffix = ("double", "MIFFT_F64", "_f64") if f64 else ("float", "MIFFT_F32", "")
+    return (f'    MIFFT_CFG("{name}{n}{suffix}_{rs}", {ty}, {dt}, {n}, {len(f)}, {r[0]}, {r[1]}, {r[2]}, {r[3]}, '
             f'{tile}, {threads}, {"true" if cols else "false"}, {"true" if fd else "false"}, '
             f'{"true" if ld else "false"}, TW_LDS, 1, false),')
 
 
+HAND_ROWS_F64 = {1024, 512, 256, 128, 64, 93, 480, 640}
+HAND_COLS_F64 = {640, 480, 128, 64, 256}
+SIZES_F64 = [n for n in SIZES if n <= 4096]
+
+
 def main():
-    rows, cols = [], []
+    rows, cols, rows64, cols64 = [], [], [], []
     for n in SIZES:
         if n not in HAND_ROWS:
             c = row_cfg(n)
@@ -124,10 +136,21 @@ def main():
             c = col_cfg(n)
             if c:
                 cols.append(emit("cols", n, c[0], c[1], c[2], True, True, True))
+    for n in SIZES_F64:
+        if n not in HAND_ROWS_F64:
+            c = row_cfg(n, True)
+            if c:
+                rows64.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], True))
+        if n not in HAND_COLS_F64 and n <= 2048:
+            c = col_cfg(n, True)
+            if c:
+                cols64.append(emit("cols", n, c[0], c[1], c[2], True, True, True, True))
     hdr = "// GENERATED by tools/gen_fast_table.py -- do not edit.\n"
     open(os.path.join(OUT, "fast_table_gen_rows.inc"), "w").write(hdr + "\n".join(rows) + "\n")
     open(os.path.join(OUT, "fast_table_gen_cols.inc"), "w").write(hdr + "\n".join(cols) + "\n")
-    print(len(rows), "row configs,", len(cols), "column configs")
+    open(os.path.join(OUT, "fast_table_gen_rows_f64.inc"), "w").write(hdr + "\n".join(rows64) + "\n")
+    open(os.path.join(OUT, "fast_table_gen_cols_f64.inc"), "w").write(hdr + "\n".join(cols64) + "\n")
+    print(len(rows), "row configs,", len(cols), "column configs,", len(rows64), "f64 rows,", len(cols64), "f64 cols")
     for l in rows[:60]:
         print(l.strip()[:110])
 
