@@ -38,6 +38,11 @@ WORKLOADS = {
     "1d_500kx128": ((500000, 128), None, 0),
     "2d_100x640x480": ((100, 640, 480), None, 3),
     "3d_10x128x128x128": ((10, 128, 128, 128), None, 4),
+    # further shapes of the reference's own bench / README tables (not BASELINE configs; index -1)
+    "3d_100x64x64x64": ((100, 64, 64, 64), None, -1),
+    "3d_1x256x256x256": ((1, 256, 256, 256), None, -1),
+    "1d_100x16384": ((100, 16384), None, -1),
+    "1d_64x1048576_fourstep": ((64, 1 << 20), None, -1),
 }
 DEFAULT_WORKLOAD = "1d_100kx1024_radix2"
 

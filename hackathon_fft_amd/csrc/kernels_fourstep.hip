@@ -1,0 +1,195 @@
+// kernels_fourstep.hip -- a contiguous dimension longer than one workgroup's LDS row (> 16 384 points).
+//
+// N = N1 * N2, x viewed as [N1][N2] (n = n1*N2 + n2):
+//   pass 1  column FFTs of length N1 (stride N2)            x       -> scratch   A[k1][n2]
+//   pass 2  transpose + twiddle  C[n2][k1] = A[k1][n2] * W_N^{k1*n2}  scratch -> out
+//   pass 3  column FFTs of length N2 (stride N1), in place   out               X[k1 + N1*k2] at [k2][k1]
+// which leaves the spectrum in natural order with no trailing transpose; both FFT passes are the in-place
+// column-tile kernels that already serve the strided dimensions of N-D transforms.  The reference has no
+// equivalent off NVIDIA thread-block clusters (fft/fft/_ndim_fft_gpu.mojo:100-108, 510-519); this is
+// SURVEY.md 8(f) item 3.  W_N^m comes from a two-level table W_N^{m mod L} * W_N^{L*(m div L)}, L = 1024,
+// both factors rounded once from long double (k1*n2 < N, so no modular reduction is needed).
+#include <cmath>
+
+#include "fft_radix.h"
+#include "mifft_internal.h"
+
+namespace mifft {
+
+static constexpr int kL = 1024;
+
+struct TTParams {
+    const void* src;
+    void* dst;
+    const void* tlo;  // W_N^l, l in [0, L)
+    const void* thi;  // W_N^{L*h}, h in [0, ceil(N/L))
+    long long n1, n2, batch;
+    int inverse;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_twiddle_kernel(const TTParams p) {
+    using V = cpx<T>;
+    __shared__ V tile[32][33];
+    const V* src = (const V*)p.src;
+    V* dst = (V*)p.dst;
+    const V* tlo = (const V*)p.tlo;
+    const V* thi = (const V*)p.thi;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+    for (long long b = blockIdx.z; b < p.batch; b += gridDim.z) {
+        const V* s = src + b * p.n1 * p.n2;
+        V* d = dst + b * p.n1 * p.n2;
+#pragma unroll
+        for (int i = 0; i < 32; i += 8) {
+            const long long k1 = r0 + ty + i, n2 = c0 + tx;
+            if (k1 < p.n1 && n2 < p.n2) {
+                V v = s[k1 * p.n2 + n2];
+                const long long m = k1 * n2;  // < N
+                V wl = tlo[m & (kL - 1)], wh = thi[m >> 10];
+                V w = cmul(wl, wh);
+                if (p.inverse) w.y = -w.y;
+                tile[ty + i][tx] = cmul(v, w);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 32; i += 8) {
+            const long long n2 = c0 + ty + i, k1 = r0 + tx;
+            if (k1 < p.n1 && n2 < p.n2) d[n2 * p.n1 + k1] = tile[tx][ty + i];
+        }
+        __syncthreads();
+    }
+}
+
+static int launch_transpose_twiddle(const Plan& plan, const DimPass& pass, const void* in, void* out, int64_t count,
+                                    hipStream_t stream) {
+    if (count == 0) return MIFFT_OK;
+    TTParams tp{};
+    tp.src = in;
+    tp.dst = out;
+    tp.tlo = pass.d_aux;
+    tp.thi = pass.d_aux2;
+    tp.n1 = pass.fs_n1;
+    tp.n2 = pass.fs_n2;
+    tp.batch = count;
+    tp.inverse = plan.inverse;
+    dim3 grid((unsigned)((pass.fs_n2 + 31) / 32), (unsigned)((pass.fs_n1 + 31) / 32),
+              (unsigned)(count < 4096 ? count : 4096));
+    if (plan.out_dtype == MIFFT_F32)
+        hipLaunchKernelGGL(transpose_twiddle_kernel<float>, grid, dim3(256), 0, stream, tp);
+    else
+        hipLaunchKernelGGL(transpose_twiddle_kernel<double>, grid, dim3(256), 0, stream, tp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_error(e, "transpose_twiddle launch");
+    return MIFFT_OK;
+}
+
+template <typename T>
+static hipError_t upload_two_level(int64_t N, void** d_lo, void** d_hi) {
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    const int64_t nhi = (N + kL - 1) / kL;
+    std::vector<T> lo(2 * kL), hi(2 * (size_t)nhi);
+    for (int64_t l = 0; l < kL; ++l) {
+        long double th = -two_pi * (long double)l / (long double)N;
+        lo[2 * l] = (T)cosl(th);
+        lo[2 * l + 1] = (T)sinl(th);
+    }
+    for (int64_t h = 0; h < nhi; ++h) {
+        long double th = -two_pi * (long double)(h * kL) / (long double)N;
+        hi[2 * h] = (T)cosl(th);
+        hi[2 * h + 1] = (T)sinl(th);
+    }
+    hipError_t e = hipMalloc(d_lo, lo.size() * sizeof(T));
+    if (e == hipSuccess) e = hipMemcpy(*d_lo, lo.data(), lo.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(d_hi, hi.size() * sizeof(T));
+    if (e == hipSuccess) e = hipMemcpy(*d_hi, hi.data(), hi.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+// one column-tile pass of length n with element stride `inner`: fused table first, literal-stage fallback
+static bool make_cols_pass(const Plan& plan, int dim_index, int64_t n, int64_t inner, DimPass& ps, std::string& why) {
+    ps = DimPass();
+    ps.dim_index = dim_index;
+    ps.N = n;
+    ps.inner = inner;
+    ps.outer = 1;
+    ps.first = false;
+    if (select_fast(plan, ps)) return true;
+    std::vector<uint64_t> user = plan_estimate_bases((uint64_t)n, true);
+    std::string err;
+    if (plan_ordered_bases((uint64_t)n, user, ps.radices, ps.processed, err) != MIFFT_OK) {
+        why = "factor " + std::to_string(n) + ": " + err;
+        return false;
+    }
+    return select_generic(plan, ps, why);
+}
+
+bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
+    const int64_t N = plan.dims[dim_index];
+    if (plan.in_components != 2 || plan.in_dtype != plan.out_dtype) {
+        why_not = "needs complex input of the output dtype";
+        return false;
+    }
+    // N = N1 * N2, both factors at most 4096, as balanced as possible, preferring lengths with fused kernels
+    int64_t best1 = 0, best2 = 0;
+    double best_score = 1e300;
+    for (int64_t n2 = 2; n2 <= 4096 && n2 < N; ++n2) {
+        if (N % n2) continue;
+        const int64_t n1 = N / n2;
+        if (n1 > 4096 || n1 < 2) continue;
+        DimPass a, b;
+        std::string w;
+        Plan probe = plan;  // selection only reads the plan
+        probe.passes.clear();
+        const bool fa = make_cols_pass(probe, dim_index, n1, n2, a, w) && std::string(a.kernel_name) != "generic";
+        const bool fb = make_cols_pass(probe, dim_index, n2, n1, b, w) && std::string(b.kernel_name) != "generic";
+        double score = std::fabs(std::log((double)n1 / (double)n2)) + (fa ? 0 : 4) + (fb ? 0 : 4);
+        if (score < best_score) {
+            best_score = score;
+            best1 = n1;
+            best2 = n2;
+        }
+    }
+    if (!best1) {
+        why_not = "no factorisation N1 * N2 with both factors <= 4096";
+        return false;
+    }
+    DimPass p1, p3, p2;
+    if (!make_cols_pass(plan, dim_index, best1, best2, p1, why_not)) return false;
+    if (!make_cols_pass(plan, dim_index, best2, best1, p3, why_not)) return false;
+    p1.src_buf = 0;  // x
+    p1.dst_buf = 2;  // scratch
+    p3.src_buf = 1;  // out, in place
+    p3.dst_buf = 1;
+    p2.dim_index = dim_index;
+    p2.N = N;
+    p2.fs_n1 = best1;
+    p2.fs_n2 = best2;
+    p2.kernel_name = "transpose_twiddle";
+    p2.launch = launch_transpose_twiddle;
+    p2.src_buf = 2;
+    p2.dst_buf = 1;
+
+    const bool inv = plan.inverse != 0;
+    hipError_t e = hipSuccess;
+    if (p1.prepare && p1.prepare() != MIFFT_OK) return false;
+    if (p3.prepare && p3.prepare() != MIFFT_OK) return false;
+    e = upload_twiddle_table(plan.out_dtype, p1.N, inv, &p1.d_twiddle);
+    if (e == hipSuccess) e = upload_twiddle_table(plan.out_dtype, p3.N, inv, &p3.d_twiddle);
+    if (e == hipSuccess)
+        e = plan.out_dtype == MIFFT_F32 ? upload_two_level<float>(N, &p2.d_aux, &p2.d_aux2)
+                                        : upload_two_level<double>(N, &p2.d_aux, &p2.d_aux2);
+    plan.scratch_bytes = (size_t)plan.batch * (size_t)plan.prod * plan.out_elem_bytes();
+    if (e == hipSuccess && plan.scratch_bytes) e = hipMalloc(&plan.d_scratch, plan.scratch_bytes);
+    plan.passes.push_back(p1);
+    plan.passes.push_back(p2);
+    plan.passes.push_back(p3);
+    if (e != hipSuccess) {
+        why_not = std::string("device allocation: ") + hipGetErrorString(e);
+        return false;
+    }
+    return true;
+}
+
+}  // namespace mifft

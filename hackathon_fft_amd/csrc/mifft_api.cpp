@@ -60,8 +60,27 @@ static void free_plan_device(Plan& p) {
     for (auto& ps : p.passes) {
         if (ps.d_twiddle) (void)hipFree(ps.d_twiddle);
         if (ps.d_aux) (void)hipFree(ps.d_aux);
-        ps.d_twiddle = ps.d_aux = nullptr;
+        if (ps.d_aux2) (void)hipFree(ps.d_aux2);
+        ps.d_twiddle = ps.d_aux = ps.d_aux2 = nullptr;
     }
+    if (p.d_scratch) (void)hipFree(p.d_scratch);
+    p.d_scratch = nullptr;
+}
+
+hipError_t upload_twiddle_table(int out_dtype, int64_t N, bool inverse, void** d_table) {
+    hipError_t err;
+    if (out_dtype == MIFFT_F32) {
+        std::vector<float> tab;
+        fill_twiddles(tab, N, inverse);
+        err = hipMalloc(d_table, tab.size() * sizeof(float));
+        if (err == hipSuccess) err = hipMemcpy(*d_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    } else {
+        std::vector<double> tab;
+        fill_twiddles(tab, N, inverse);
+        err = hipMalloc(d_table, tab.size() * sizeof(double));
+        if (err == hipSuccess) err = hipMemcpy(*d_table, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+    }
+    return err;
 }
 
 static int device_count_quiet() {
@@ -201,21 +220,7 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
     // ---- passes in execution order: last dimension first ----
     p.stage_radices = ordered;
     auto upload_twiddles = [&](DimPass& ps) -> hipError_t {
-        hipError_t err;
-        if (out_dtype == MIFFT_F32) {
-            std::vector<float> tab;
-            fill_twiddles(tab, ps.N, inverse != 0);
-            err = hipMalloc(&ps.d_twiddle, tab.size() * sizeof(float));
-            if (err == hipSuccess)
-                err = hipMemcpy(ps.d_twiddle, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
-        } else {
-            std::vector<double> tab;
-            fill_twiddles(tab, ps.N, inverse != 0);
-            err = hipMalloc(&ps.d_twiddle, tab.size() * sizeof(double));
-            if (err == hipSuccess)
-                err = hipMemcpy(ps.d_twiddle, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
-        }
-        return err;
+        return upload_twiddle_table(out_dtype, ps.N, inverse != 0, &ps.d_twiddle);
     };
     for (int i = ndim - 1; i >= 0; --i) {
         DimPass ps;
@@ -248,9 +253,13 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
             std::string why;
             ok = select_generic(p, ps, why);
             if (!ok) {
+                // too long for one workgroup's LDS: four-step over two column-tile passes (contiguous dim of a
+                // batched 1-D complex transform; the reference has no path at all here off NVIDIA clusters)
+                std::string why4;
+                if (ndim == 1 && build_fourstep(p, i, why4)) continue;
                 free_plan_device(p);
                 delete h;
-                return set_error(MIFFT_ERR_TOO_LARGE, why);
+                return set_error(MIFFT_ERR_TOO_LARGE, why + (why4.empty() ? "" : "; four-step: " + why4));
             }
         }
         if (ps.prepare) {
@@ -289,8 +298,12 @@ int mifft_exec_batch(const mifft_plan* plan, const void* x, void* out, int64_t f
         return set_error(MIFFT_ERR_ALIAS, "x and out must not overlap");
     MIFFT_HIP_TRY(hipSetDevice(p.device));
     hipStream_t s = (hipStream_t)stream;
+    char* sb = p.d_scratch ? (char*)p.d_scratch + (size_t)first * out_row : nullptr;
+    auto buf = [&](int which) -> char* { return which == 0 ? (char*)xb : which == 2 ? sb : ob; };
     for (const DimPass& ps : p.passes) {
-        int rc = ps.launch(p, ps, ps.first ? (const void*)xb : (const void*)ob, ob, count, s);
+        const void* src = ps.src_buf >= 0 ? buf(ps.src_buf) : (ps.first ? (const char*)xb : ob);
+        void* dst = ps.dst_buf >= 0 ? buf(ps.dst_buf) : ob;
+        int rc = ps.launch(p, ps, src, dst, count, s);
         if (rc) return rc;
     }
     return MIFFT_OK;

@@ -60,6 +60,11 @@ struct DimPass {
     int threads = 256;
     size_t lds_bytes = 0;
     bool first = false;    // reads x (with in_dtype / in_components) instead of out
+    // buffer routing of the four-step passes (kernels_fourstep.hip): 0 = x, 1 = out, 2 = plan scratch;
+    // -1 = the default (first ? x : out) -> out
+    int src_buf = -1, dst_buf = -1;
+    int64_t fs_n1 = 0, fs_n2 = 0;  // four-step factors of the dimension (transpose + twiddle pass)
+    void* d_aux2 = nullptr;
 };
 
 struct Plan {
@@ -75,6 +80,9 @@ struct Plan {
     int num_cus = 256;
     std::vector<DimPass> passes;  // in execution order: last dim first
     std::vector<std::vector<uint32_t>> stage_radices;  // per dim: the user's ordered stages (introspection)
+    void* d_scratch = nullptr;  // four-step only: one tensor of the output size (the reference's calc_buf,
+                                // fft/fft/_ndim_fft_gpu.mojo:185, exists for EVERY plan; here only for dims > 16384)
+    size_t scratch_bytes = 0;
     size_t in_elem_bytes() const;
     size_t out_elem_bytes() const;  // bytes of one complex output element
 };
@@ -85,6 +93,10 @@ bool select_generic(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_fast(const Plan& plan, DimPass& pass);
 // fused pass over the two innermost dimensions (pass.N = contiguous dim, pass.N1 = the next one)
 bool select_fast_plane(const Plan& plan, DimPass& pass);
+// a contiguous dimension too long for one workgroup: three passes (column FFTs of N1, transpose + twiddle,
+// column FFTs of N2).  Appends its passes to plan.passes and allocates plan.d_scratch.
+bool build_fourstep(Plan& plan, int dim_index, std::string& why_not);
+hipError_t upload_twiddle_table(int out_dtype, int64_t N, bool inverse, void** d_table);
 
 inline size_t dtype_size(int dt) {
     switch (dt) {

@@ -198,8 +198,11 @@ def test_errors_from_the_device_side_of_the_boundary():
     with pytest.raises(mf.MifftError):
         mf.fft(torch.zeros((2, 9, 2), device=DEV), x, plan=plan)
     with pytest.raises(mf.MifftError) as e:
-        mf.plan_fft(torch.float32, torch.float32, (1, 1 << 20, 2), (1, 1 << 20, 2), bases=[[2]])
-    assert e.value.status == -9            # does not fit one workgroup's LDS (reference: unsupported too)
+        mf.plan_fft(torch.float32, torch.float32, (1, 1 << 25, 2), (1, 1 << 25, 2), bases=[[2]])
+    assert e.value.status == -9            # beyond four-step reach (4096 x 4096 points)
+    with pytest.raises(mf.MifftError) as e:
+        mf.plan_fft(torch.float32, torch.float32, (1, 1 << 20, 1), (1, 1 << 20, 2), bases=[[2]])
+    assert e.value.status == -9            # four-step takes complex input of the output dtype only
 
 
 def test_convenience_wrappers():
@@ -280,3 +283,24 @@ def test_full_size_properties(shape, bases):
     ctx.synchronize()
     lhs, rhs = fz.double(), 0.5 * out[:k].double() + fy.double()
     assert ((lhs - rhs).reshape(k, -1).norm(dim=1) / rhs.reshape(k, -1).norm(dim=1)).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("n,batch,dtype", [(32768, 3, np.float32), (65536, 2, np.float32), (1 << 20, 1, np.float32),
+                                           (100000, 3, np.float32), (98304, 2, np.float32), (20480, 5, np.float32),
+                                           (50000, 2, np.float64), (1 << 17, 1, np.float64)])
+def test_four_step_large_dimension(n, batch, dtype):
+    """Dimensions beyond one workgroup's LDS row: column FFTs, transpose + twiddle,
+    column FFTs.  Checked against fp64 pocketfft (the oracle needs minutes at these lengths)."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((batch, n, 2)).astype(dtype)
+    out, plan = gpu_fft(x, out_dtype=dtype)
+    assert not np.isnan(out).any()
+    assert plan.num_launches == 3
+    truth = np.fft.fft(to_complex(x), axis=1)
+    tol = REL_L2_TOL_F32 if dtype == np.float32 else 1e-11
+    assert rel_l2(out, from_complex(truth, np.float64)) < tol
+    back, _ = gpu_fft(out, inverse=True, out_dtype=dtype)
+    assert rel_l2(back, x) < tol
+    if batch > 1:   # a slab of the batch through the same plan
+        part, _ = gpu_fft(x, out_dtype=dtype, first=1, count=1)
+        assert np.isnan(part[0]).all() and np.array_equal(part[1], out[1])
