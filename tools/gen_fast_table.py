@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "hackathon_fft_amd", "csrc")
 
 HAND_ROWS = {1024, 512, 256, 128, 64, 2048, 4096, 93, 480, 640}
-HAND_COLS = {640, 480, 128, 64, 256}
+HAND_COLS = {640, 480, 128, 64, 256, 1024}
 
 SIZES = sorted(set(
     [2 ** k for k in range(4, 15)] +

@@ -251,6 +251,23 @@ int main(int argc, char** argv) {
         V("c128 16x8 t8 64 lds w4", float, 128, 2, 16, 8, 1, 1, 8, 64, true, true, true, TW_LDS, 4, false),
         V("c128 16x8 t16 128 lds w4 pf", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_LDS, 4, true),
     };
+#elif GROUP == 8  // ---- four-step passes: columns of 1024 over 1024 columns, 64 transforms of 2^20 ----
+    const long long batch = 64, outer = 1, inner = 1024;
+    const int N = 1024;
+    std::vector<Variant> vs = {
+        V("c1024 4x4x8x8 t8 512 lds", float, 1024, 4, 4, 4, 8, 8, 8, 512, true, true, true, TW_LDS, 1, false),
+        V("c1024 4x4x8x8 t8 512 lds pf", float, 1024, 4, 4, 4, 8, 8, 8, 512, true, true, true, TW_LDS, 1, true),
+        V("c1024 4x4x8x8 t16 1024 lds", float, 1024, 4, 4, 4, 8, 8, 16, 1024, true, true, true, TW_LDS, 1, false),
+        V("c1024 4x4x8x8 t16 512 lds", float, 1024, 4, 4, 4, 8, 8, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c1024 16x8x8 t16 1024 lds", float, 1024, 3, 16, 8, 8, 1, 16, 1024, true, true, true, TW_LDS, 1, false),
+        V("c1024 16x8x8 t16 512 lds", float, 1024, 3, 16, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c1024 8x8x16 t16 1024 lds", float, 1024, 3, 8, 8, 16, 1, 16, 1024, true, true, true, TW_LDS, 1, false),
+        V("c1024 16x8x8 t8 512 lds", float, 1024, 3, 16, 8, 8, 1, 8, 512, true, true, true, TW_LDS, 1, false),
+        V("c1024 16x8x8 t8 512 lds pf", float, 1024, 3, 16, 8, 8, 1, 8, 512, true, true, true, TW_LDS, 1, true),
+        V("c1024 16x8x8 t8 256 lds w2", float, 1024, 3, 16, 8, 8, 1, 8, 256, true, true, true, TW_LDS, 2, false),
+        V("c1024 4x4x8x8 t8 256 lds w2", float, 1024, 4, 4, 4, 8, 8, 8, 256, true, true, true, TW_LDS, 2, false),
+        V("c1024 4x4x8x8 t4 256 lds w2", float, 1024, 4, 4, 4, 8, 8, 4, 256, true, true, true, TW_LDS, 2, false),
+    };
 #elif GROUP == 7  // ---- config 5 fused z+y plane pass: 1280 planes of 128x128 ----
     const long long batch = 10, outer = 128, inner = 1;
     const int N = 128;  // tensor = batch*outer planes of 128x128 -> elems = batch*outer*128*128
