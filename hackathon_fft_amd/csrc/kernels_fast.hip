@@ -14,12 +14,17 @@ static const FastEntry kFastTable[] = {
     // streaming twin: four small-radix passes, 512 threads x 8 elements (low VGPR count, 32 waves/CU): 0.274 ms
     MIFFT_CFG_STREAM("rows1024_4x4x8x8", float, MIFFT_F32, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
-    MIFFT_CFG_CR("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
-    MIFFT_CFG_CR("rows256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, false, true, true, TW_LDS, 2, false),
+    // power-of-two rows (tools/tune GROUP 9-12, 819-MB tensors): plain 0.304-0.316 ms, streaming twins 0.277-0.295 ms
+    MIFFT_CFG_STREAM("rows512_4x4x4x8", float, MIFFT_F32, 512, 4, 4, 4, 4, 8, 8, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_CR("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_STREAM("rows256_8x8x4", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_CR("rows256_8x8x4", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_CR("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_CR("rows64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_REG, 1, false),
+    MIFFT_CFG_STREAM("rows2048_4x8x8x8", float, MIFFT_F32, 2048, 4, 4, 8, 8, 8, 2, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows2048_16x16x8", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_STREAM("rows4096_8x8x8x8", float, MIFFT_F32, 4096, 4, 8, 8, 8, 8, 1, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
     // one 128-KiB row per workgroup; twiddles from the global table (the compact LDS table would need 131 KB more)
     MIFFT_CFG("rows16384_16x16x8x8", float, MIFFT_F32, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, false),

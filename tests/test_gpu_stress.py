@@ -122,3 +122,19 @@ def test_exec_is_capturable_into_a_hip_graph(shape, kw):
     axes = tuple(range(1, len(shape)))
     truth = np_fft(x[:2], axes)
     assert ((out[:2].double().cpu() - truth).norm() / truth.norm()).item() < 1e-5
+
+
+@pytest.mark.parametrize("n", [93, 128, 256, 512, 1024, 2048, 4096])
+def test_streaming_twins_at_streaming_size(n):
+    """Above 0.6 GB of traffic per exec the plan picks the non-temporal twin (a different radix sequence for some
+    lengths): run it at that size and spot-check rows from the start, the middle and the ragged end."""
+    batch = 38_000_000 // n + 3
+    g = torch.Generator(device=DEV).manual_seed(n)
+    x = torch.randn((batch, n, 2), generator=g, device=DEV)
+    out, plan = run(x)
+    assert plan.kernel_name(0).endswith(("_nt", "_nts")), plan.kernel_name(0)
+    for lo in (0, batch // 2, batch - 5):
+        ref = np_fft(x[lo:lo + 5], (1,))
+        got = out[lo:lo + 5].double().cpu()
+        assert ((got - ref).reshape(5, -1).norm(dim=1) / ref.reshape(5, -1).norm(dim=1)).max().item() < 1e-5
+    assert not torch.isnan(out).any()

@@ -268,6 +268,63 @@ int main(int argc, char** argv) {
         V("c1024 4x4x8x8 t8 256 lds w2", float, 1024, 4, 4, 4, 8, 8, 8, 256, true, true, true, TW_LDS, 2, false),
         V("c1024 4x4x8x8 t4 256 lds w2", float, 1024, 4, 4, 4, 8, 8, 4, 256, true, true, true, TW_LDS, 2, false),
     };
+#elif GROUP == 9  // ---- rows of 256, 400k transforms ----
+    const long long batch = 400000, outer = 1, inner = 1;
+    const int N = 256;
+    std::vector<Variant> vs = {
+        VN("16x16 t16 256 lds w2 nt0", 0, float, 256, 2, 16, 16, 1, 1, 16, 256, false, true, true, TW_LDS, 2, false),
+        VN("16x16 t16 256 lds w2 nt3", 3, float, 256, 2, 16, 16, 1, 1, 16, 256, false, true, true, TW_LDS, 2, false),
+        VN("16x16 t16 256 reg w2 nt3", 3, float, 256, 2, 16, 16, 1, 1, 16, 256, false, true, true, TW_REG, 2, false),
+        VN("4x8x8 t16 512 lds w2 nt3", 3, float, 256, 3, 4, 8, 8, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x8x8 t16 256 lds w4 nt3", 3, float, 256, 3, 4, 8, 8, 1, 16, 256, false, true, true, TW_LDS, 4, false),
+        VN("8x8x4 t16 512 lds w2 nt3", 3, float, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x4x4x4 t16 512 lds w2 nt3", 3, float, 256, 4, 4, 4, 4, 4, 16, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x4x4x4 t16 1024 lds w4 nt3", 3, float, 256, 4, 4, 4, 4, 4, 16, 1024, false, true, true, TW_LDS, 4, false),
+        VN("8x8x4 t8 256 lds w4 nt3", 3, float, 256, 3, 8, 8, 4, 1, 8, 256, false, true, true, TW_LDS, 4, false),
+        VN("8x8x4 t16 512 lds w2 nt0", 0, float, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+    };
+#elif GROUP == 10  // ---- rows of 512, 200k transforms ----
+    const long long batch = 200000, outer = 1, inner = 1;
+    const int N = 512;
+    std::vector<Variant> vs = {
+        VN("8x8x8 t4 256 lds w4 nt0", 0, float, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VN("8x8x8 t4 256 lds w4 nt3", 3, float, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VN("8x8x8 t8 512 lds w2 nt3", 3, float, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+        VN("8x8x8 t8 256 lds w2 nt3", 3, float, 512, 3, 8, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, false),
+        VN("4x4x4x8 t8 512 lds w2 nt3", 3, float, 512, 4, 4, 4, 4, 8, 8, 512, false, true, true, TW_LDS, 2, false),
+        VN("16x8x4 t8 256 lds w2 nt3", 3, float, 512, 3, 16, 8, 4, 1, 8, 256, false, true, true, TW_LDS, 2, false),
+        VN("16x32 t8 256 lds w2 nt3", 3, float, 512, 2, 16, 32, 1, 1, 8, 256, false, true, true, TW_LDS, 2, false),
+        VN("8x8x8 t4 256 reg w2 pf nt3", 3, float, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
+        VN("8x8x8 t8 512 lds w2 nt0", 0, float, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+    };
+#elif GROUP == 11  // ---- rows of 2048, 50k transforms ----
+    const long long batch = 50000, outer = 1, inner = 1;
+    const int N = 2048;
+    std::vector<Variant> vs = {
+        VN("16x16x8 t2 256 lds w2 nt0", 0, float, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
+        VN("16x16x8 t2 256 lds w2 nt3", 3, float, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
+        VN("16x16x8 t2 256 lds w4 nt3", 3, float, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 4, false),
+        VN("4x8x8x8 t2 512 lds w2 nt3", 3, float, 2048, 4, 4, 8, 8, 8, 2, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x8x8x8 t4 1024 lds w4 nt3", 3, float, 2048, 4, 4, 8, 8, 8, 4, 1024, false, true, true, TW_LDS, 4, false),
+        VN("4x8x8x8 t1 256 lds w4 nt3", 3, float, 2048, 4, 4, 8, 8, 8, 1, 256, false, true, true, TW_LDS, 4, false),
+        VN("16x16x8 t1 128 lds w4 nt3", 3, float, 2048, 3, 16, 16, 8, 1, 1, 128, false, true, true, TW_LDS, 4, false),
+        VN("8x16x16 t2 256 lds w4 nt3", 3, float, 2048, 3, 8, 16, 16, 1, 2, 256, false, true, true, TW_LDS, 4, false),
+        VN("4x8x8x8 t2 512 lds w2 nt0", 0, float, 2048, 4, 4, 8, 8, 8, 2, 512, false, true, true, TW_LDS, 2, false),
+    };
+#elif GROUP == 12  // ---- rows of 4096, 25k transforms ----
+    const long long batch = 25000, outer = 1, inner = 1;
+    const int N = 4096;
+    std::vector<Variant> vs = {
+        VN("16x16x16 t1 256 lds w2 nt0", 0, float, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
+        VN("16x16x16 t1 256 lds w2 nt3", 3, float, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
+        VN("16x16x16 t1 256 lds w4 nt3", 3, float, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 4, false),
+        VN("8x8x8x8 t1 512 lds w2 nt3", 3, float, 4096, 4, 8, 8, 8, 8, 1, 512, false, true, true, TW_LDS, 2, false),
+        VN("8x8x8x8 t2 1024 lds w4 nt3", 3, float, 4096, 4, 8, 8, 8, 8, 2, 1024, false, true, true, TW_LDS, 4, false),
+        VN("8x8x8x8 t1 256 lds w4 nt3", 3, float, 4096, 4, 8, 8, 8, 8, 1, 256, false, true, true, TW_LDS, 4, false),
+        VN("4x4x16x16 t1 512 lds w2 nt3", 3, float, 4096, 4, 4, 4, 16, 16, 1, 512, false, true, true, TW_LDS, 2, false),
+        VN("16x16x16 t2 512 lds w2 nt3", 3, float, 4096, 3, 16, 16, 16, 1, 2, 512, false, true, true, TW_LDS, 2, false),
+        VN("8x8x8x8 t1 512 lds w2 nt0", 0, float, 4096, 4, 8, 8, 8, 8, 1, 512, false, true, true, TW_LDS, 2, false),
+    };
 #elif GROUP == 7  // ---- config 5 fused z+y plane pass: 1280 planes of 128x128 ----
     const long long batch = 10, outer = 128, inner = 1;
     const int N = 128;  // tensor = batch*outer planes of 128x128 -> elems = batch*outer*128*128
