@@ -42,6 +42,9 @@ WORKLOADS = {
     "3d_100x64x64x64": ((100, 64, 64, 64), None, -1),
     "3d_1x256x256x256": ((1, 256, 256, 256), None, -1),
     "1d_100x16384": ((100, 16384), None, -1),
+    "2d_10x1920x1080": ((10, 1920, 1080), None, -1),
+    "2d_1x3840x2160": ((1, 3840, 2160), None, -1),
+    "2d_1x7680x4320": ((1, 7680, 4320), None, -1),
     "1d_64x1048576_fourstep": ((64, 1 << 20), None, -1),
 }
 DEFAULT_WORKLOAD = "1d_100kx1024_radix2"

@@ -134,6 +134,7 @@ struct TileCfg {
     static constexpr size_t LDS_BYTES =
         DMA_ ? (size_t)(STAGE_OFF + STAGE_ELEMS) * 2 * sizeof(T_) : (size_t)(DATA_ELEMS + TWL_TOTAL) * 2 * sizeof(T_);
     static_assert(P(NP_) == N_, "radices must multiply to N");
+    static_assert(LDS_BYTES <= 160 * 1024, "tile + twiddle table exceed the CU's 160 KiB of LDS");
 };
 
 // XOR swizzle of the in-row index for the exchange written by pass E (power-of-two rows

@@ -23,8 +23,8 @@ HAND_COLS = {640, 480, 128, 64, 256, 1024}
 SIZES = sorted(set(
     [2 ** k for k in range(4, 15)] +
     [24, 40, 48, 60, 72, 80, 96, 100, 120, 144, 160, 192, 200, 240, 250, 320, 360, 384, 400, 500, 600, 720, 768, 800,
-     960, 1000, 1080, 1200, 1280, 1440, 1536, 1920, 2000, 2160, 2400, 2560, 3000, 3072, 3200, 3840, 4000, 6144,
-     7680]))
+     900, 960, 1000, 1080, 1200, 1280, 1440, 1536, 1600, 1920, 2000, 2160, 2400, 2560, 2880, 3000, 3072, 3200, 3840,
+     4000, 4320, 5120, 6144, 7680]))
 
 ALLOWED = [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 15, 16]
 
@@ -95,19 +95,47 @@ def row_cfg(n, f64=False):
     return f, tile, threads, fd, ld
 
 
+def twl_entries(f):
+    """entries of the compact LDS twiddle table: sum over passes k >= 1 of P_k * (R_k - 1)"""
+    tot, p = 0, 1
+    for k, r in enumerate(f):
+        if k >= 1:
+            tot += p * (r - 1)
+        p *= r
+    return tot
+
+
+def choose3(n, allowed):
+    """3 passes, radices <= 16, ascending (column tiles with 32 elements per thread spill with 4 passes)"""
+    best = None
+    for f in factorizations(n, 3, [a for a in (allowed or ALLOWED) if a <= 16]):
+        score = (max(f), -min(f))
+        if best is None or score < best[0]:
+            best = (score, f)
+    return sorted(best[1]) if best else None
+
+
 def col_cfg(n, f64=False):
     f = choose(n, True, ALLOWED_F64 if f64 else None)
     if f is None:
         return None
+    big = n * (8 if f64 else 16) > (4096 if f64 else 8192)   # would need > 16 (8) elements per thread at 16 columns
+    if big:
+        f3 = choose3(n, ALLOWED_F64 if f64 else None)
+        if f3 is not None:
+            f = f3
     tile = 8 if f64 else 16                 # 128-byte HBM runs
     esz = 16 if f64 else 8
-    cap = 4096 if f64 else 8192             # <= 512 threads and <= 16 (8 for f64) elements per thread
-    while (n * tile > cap or n * tile * esz > 128 * 1024) and tile > 2:
+    # <= 512 threads; up to 32 (16 for f64) elements per thread for 3-pass configurations (4-pass ones spill)
+    cap = (8192 if f64 else 16384) if len(f) <= 3 else (4096 if f64 else 8192)
+    while (n * tile > cap or n * tile * esz > 136 * 1024) and tile > 2:
         tile //= 2
     if n * tile > cap:
         return None
     per = 10 if f64 else 20
     threads = max(128, min(512, pow2ceil((n * tile + per - 1) // per)))
+    if n * tile * esz > 136 * 1024:
+        return None
     return f, tile, threads
 
 
@@ -115,9 +143,12 @@ def emit(name, n, f, tile, threads, cols, fd, ld, f64=False):
     r = list(f) + [1] * (4 - len(f))
     rs = "x".join(str(v) for v in f)
     ty, dt, suffix = ("double", "MIFFT_F64", "_f64") if f64 else ("float", "MIFFT_F32", "")
+    esz = 16 if f64 else 8
+    # the compact twiddle table must fit next to the tile (160 KiB per workgroup); else read the global table
+    twm = "TW_LDS" if (n * tile + twl_entries(f)) * esz <= 156 * 1024 else "TW_GLOBAL"
     return (f'    MIFFT_CFG("{name}{n}{suffix}_{rs}", {ty}, {dt}, {n}, {len(f)}, {r[0]}, {r[1]}, {r[2]}, {r[3]}, '
             f'{tile}, {threads}, {"true" if cols else "false"}, {"true" if fd else "false"}, '
-            f'{"true" if ld else "false"}, TW_LDS, 1, false),')
+            f'{"true" if ld else "false"}, {twm}, 1, false),')
 
 
 HAND_ROWS_F64 = {1024, 512, 256, 128, 64, 93, 480, 640}
@@ -132,7 +163,7 @@ def main():
             c = row_cfg(n)
             if c:
                 rows.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4]))
-        if n not in HAND_COLS and n <= 4096:
+        if n not in HAND_COLS and n <= 8192:
             c = col_cfg(n)
             if c:
                 cols.append(emit("cols", n, c[0], c[1], c[2], True, True, True))
