@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--faithful", action="store_true", help="force the literal stage-per-pass kernel family")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="arithmetic type (BASELINE metric: f32)")
     args = ap.parse_args()
 
     import torch
@@ -163,19 +164,20 @@ def main():
     shape, bases, cfg_idx = WORKLOADS[args.workload]
     dev = torch.device("cuda", local_rank)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(tuple(shape) + (2,), generator=gen, device=dev, dtype=torch.float32)
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    esz = 4 if args.dtype == "f32" else 8
+    x = torch.randn(tuple(shape) + (2,), generator=gen, device=dev, dtype=tdt)
     out = torch.empty_like(x)
     ctx = mf.DeviceContext(local_rank)
     if distributed:
         # weak scaling: the global problem is world x (per-GPU shape); every rank owns one resident slab
         from hackathon_fft_amd.dist import ShardedFFT
         gshape = (shape[0] * world,) + tuple(shape[1:]) + (2,)
-        sharded = ShardedFFT(torch.float32, torch.float32, gshape, gshape, bases=bases, device=local_rank)
+        sharded = ShardedFFT(tdt, tdt, gshape, gshape, bases=bases, device=local_rank)
         assert sharded.slab_in_shape == tuple(x.shape)
         plan, ctx = sharded._backend.plan, sharded._backend.ctx
     else:
-        plan = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, bases=bases, ctx=ctx,
-                           faithful_stages=args.faithful)
+        plan = mf.plan_fft(tdt, tdt, x.shape, x.shape, bases=bases, ctx=ctx, faithful_stages=args.faithful)
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,7 +208,7 @@ def main():
         elems = 1
         for d in shape:
             elems *= d
-        algo_bytes = 16.0 * elems  # per launch sequence on ONE gpu
+        algo_bytes = 4.0 * esz * elems  # one complex read + one complex write per element, per exec on ONE gpu
         achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
         kernels = [plan.kernel_name(d) for d in range(len(shape) - 1)]
         traffic = measured_traffic(args.workload, kernels)
@@ -222,7 +224,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": args.workload,
@@ -248,7 +250,7 @@ def main():
                 "launch_ms_hip_events": round(launch_ms, 5),
             },
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and args.dtype == "f32":
             result["cpu_baseline"] = cpu_baseline(shape, bases)
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()

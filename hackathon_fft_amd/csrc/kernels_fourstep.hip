@@ -25,6 +25,7 @@ struct TTParams {
     const void* thi;  // W_N^{L*h}, h in [0, ceil(N/L))
     long long n1, n2, batch;
     int inverse;
+    int apply_tw;  // 0: plain batched transpose (long strided dimensions), 1: four-step twiddle W_N^{k1*n2}
 };
 
 template <typename T>
@@ -45,11 +46,14 @@ __global__ __launch_bounds__(256) void transpose_twiddle_kernel(const TTParams p
             const long long k1 = r0 + ty + i, n2 = c0 + tx;
             if (k1 < p.n1 && n2 < p.n2) {
                 V v = s[k1 * p.n2 + n2];
-                const long long m = k1 * n2;  // < N
-                V wl = tlo[m & (kL - 1)], wh = thi[m >> 10];
-                V w = cmul(wl, wh);
-                if (p.inverse) w.y = -w.y;
-                tile[ty + i][tx] = cmul(v, w);
+                if (p.apply_tw) {
+                    const long long m = k1 * n2;  // < N
+                    V wl = tlo[m & (kL - 1)], wh = thi[m >> 10];
+                    V w = cmul(wl, wh);
+                    if (p.inverse) w.y = -w.y;
+                    v = cmul(v, w);
+                }
+                tile[ty + i][tx] = v;
             }
         }
         __syncthreads();
@@ -72,10 +76,11 @@ static int launch_transpose_twiddle(const Plan& plan, const DimPass& pass, const
     tp.thi = pass.d_aux2;
     tp.n1 = pass.fs_n1;
     tp.n2 = pass.fs_n2;
-    tp.batch = count;
+    tp.batch = count * pass.outer;  // matrices per exec (outer = 1 for the four-step)
     tp.inverse = plan.inverse;
+    tp.apply_tw = pass.d_aux != nullptr;
     dim3 grid((unsigned)((pass.fs_n2 + 31) / 32), (unsigned)((pass.fs_n1 + 31) / 32),
-              (unsigned)(count < 4096 ? count : 4096));
+              (unsigned)(tp.batch < 4096 ? tp.batch : 4096));
     if (plan.out_dtype == MIFFT_F32)
         hipLaunchKernelGGL(transpose_twiddle_kernel<float>, grid, dim3(256), 0, stream, tp);
     else
@@ -185,6 +190,64 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
     plan.passes.push_back(p1);
     plan.passes.push_back(p2);
     plan.passes.push_back(p3);
+    if (e != hipSuccess) {
+        why_not = std::string("device allocation: ") + hipGetErrorString(e);
+        return false;
+    }
+    return true;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// A STRIDED dimension too long for a column tile (N > 4096: 8K-video columns, ...): transpose the
+// [N][inner] matrices into the plan scratch, run the contiguous-row kernel of length N there, transpose
+// back.  Three passes, each fully coalesced -- the reference's own transpose / FFT / transpose scheme
+// (fft/fft/_ndim_fft_gpu.mojo:634-642), used here only where an in-place column tile cannot be built.
+// ---------------------------------------------------------------------------------------------
+bool build_transposed_dim(Plan& plan, int dim_index, const std::vector<uint32_t>& radices,
+                          const std::vector<uint32_t>& processed, std::string& why_not) {
+    const int64_t N = plan.dims[dim_index];
+    int64_t inner = 1, outer = 1;
+    for (int k = dim_index + 1; k < plan.ndim; ++k) inner *= plan.dims[k];
+    for (int k = 0; k < dim_index; ++k) outer *= plan.dims[k];
+    if (inner == 1) {
+        why_not = "contiguous dimension";
+        return false;
+    }
+    DimPass rows;
+    rows.dim_index = dim_index;
+    rows.N = N;
+    rows.inner = 1;
+    rows.outer = outer * inner;  // rows of the transposed tensor per batch entry
+    rows.radices = radices;
+    rows.processed = processed;
+    rows.first = false;
+    if (!select_fast(plan, rows) && !select_generic(plan, rows, why_not)) return false;
+    rows.src_buf = 2;
+    rows.dst_buf = 2;
+    DimPass t_in, t_out;
+    t_in.dim_index = t_out.dim_index = dim_index;
+    t_in.N = t_out.N = N;
+    t_in.outer = t_out.outer = outer;
+    t_in.kernel_name = t_out.kernel_name = "transpose";
+    t_in.launch = t_out.launch = launch_transpose_twiddle;
+    t_in.fs_n1 = N;       // out [N][inner] -> scratch [inner][N]
+    t_in.fs_n2 = inner;
+    t_in.src_buf = 1;
+    t_in.dst_buf = 2;
+    t_out.fs_n1 = inner;  // scratch [inner][N] -> out [N][inner]
+    t_out.fs_n2 = N;
+    t_out.src_buf = 2;
+    t_out.dst_buf = 1;
+    if (rows.prepare && rows.prepare() != MIFFT_OK) return false;
+    hipError_t e = upload_twiddle_table(plan.out_dtype, N, plan.inverse != 0, &rows.d_twiddle);
+    if (e == hipSuccess && !plan.d_scratch) {
+        plan.scratch_bytes = (size_t)plan.batch * (size_t)plan.prod * plan.out_elem_bytes();
+        if (plan.scratch_bytes) e = hipMalloc(&plan.d_scratch, plan.scratch_bytes);
+    }
+    plan.passes.push_back(t_in);
+    plan.passes.push_back(rows);
+    plan.passes.push_back(t_out);
     if (e != hipSuccess) {
         why_not = std::string("device allocation: ") + hipGetErrorString(e);
         return false;

@@ -248,6 +248,12 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                 }
             }
             if (!ok) ok = select_fast(p, ps);
+            // long strided dimension without a fused column tile: transposes + the contiguous-row kernel beat the
+            // literal-stage column fallback by an order of magnitude (and lift its 10 240-point limit)
+            if (!ok && ps.inner != 1 && ps.N > 4096) {
+                std::string whyt;
+                if (build_transposed_dim(p, i, ordered[i], processed[i], whyt)) continue;
+            }
         }
         if (!ok) {
             std::string why;

@@ -96,6 +96,9 @@ bool select_fast_plane(const Plan& plan, DimPass& pass);
 // a contiguous dimension too long for one workgroup: three passes (column FFTs of N1, transpose + twiddle,
 // column FFTs of N2).  Appends its passes to plan.passes and allocates plan.d_scratch.
 bool build_fourstep(Plan& plan, int dim_index, std::string& why_not);
+// a strided dimension too long for an in-place column tile: transpose -> row kernel -> transpose through the scratch
+bool build_transposed_dim(Plan& plan, int dim_index, const std::vector<uint32_t>& radices,
+                          const std::vector<uint32_t>& processed, std::string& why_not);
 hipError_t upload_twiddle_table(int out_dtype, int64_t N, bool inverse, void** d_table);
 
 inline size_t dtype_size(int dt) {

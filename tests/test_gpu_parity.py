@@ -304,3 +304,17 @@ def test_four_step_large_dimension(n, batch, dtype):
     if batch > 1:   # a slab of the batch through the same plan
         part, _ = gpu_fft(x, out_dtype=dtype, first=1, count=1)
         assert np.isnan(part[0]).all() and np.array_equal(part[1], out[1])
+
+
+@pytest.mark.parametrize("shape", [(1, 7680, 64), (2, 5120, 40), (1, 8192, 3, 5), (1, 6144, 100)])
+def test_long_strided_dimension_through_transposes(shape):
+    """A strided dimension beyond the column-tile table (8K-video columns): transpose -> row kernel -> transpose
+    through the plan scratch."""
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape + (2,)).astype(np.float32)
+    out, plan = gpu_fft(x, out_dtype=np.float32)
+    assert plan.kernel_name(0) == "transpose"
+    truth = np.fft.fftn(to_complex(x), axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
+    back, _ = gpu_fft(out, inverse=True, out_dtype=np.float32)
+    assert rel_l2(back, x) < REL_L2_TOL_F32
