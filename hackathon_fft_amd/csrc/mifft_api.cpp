@@ -360,18 +360,18 @@ int mifft_time_exec(const mifft_plan* plan, const void* x, void* out, void* stre
     if (iters < 1) iters = 1;
     MIFFT_HIP_TRY(hipSetDevice(plan->p.device));
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    MIFFT_HIP_TRY(hipEventCreate(&e0));
-    MIFFT_HIP_TRY(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
     int rc = MIFFT_OK;
-    hipError_t he = hipEventRecord(e0, s);
+    if (he == hipSuccess) he = hipEventRecord(e0, s);
     for (int i = 0; i < iters && rc == MIFFT_OK && he == hipSuccess; ++i) rc = mifft_exec(plan, x, out, stream);
     if (he == hipSuccess) he = hipEventRecord(e1, s);
     if (he == hipSuccess) he = hipEventSynchronize(e1);
     float ms = 0.f;
     if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     if (rc) return rc;
     if (he != hipSuccess) return hip_error(he, "mifft_time_exec events");
     *ms_out = ms / (float)iters;
