@@ -144,6 +144,8 @@ Variant make_plane(const char* name) {
 #define V(NAME, ...) make<TileCfg<__VA_ARGS__>>(NAME)
 // explicit non-temporal mode: ... PF, then NT (0 none, 1 loads, 2 stores, 3 both)
 #define VN(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, false, false, NT>>(NAME)
+// ... with an LDS row pad (ROWS: pitch = N + PAD)
+#define VNP(NAME, NT, PAD, ...) make<TileCfg<__VA_ARGS__, PAD, false, false, NT>>(NAME)
 // DMA-staged flat-copy rows: T N NP R0..R3 TILE THREADS TWMODE MINW
 #define DS(NAME, G, NTM, T, N, NP, R0, R1, R2, R3, TILE, THR, TWM, MINW) \
     make_dma_split<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THR, false, false, false, TWM, MINW, false, 0, false, true, NTM>, G>(NAME)
@@ -181,19 +183,16 @@ int main(int argc, char** argv) {
     const long long batch = 500000, outer = 1, inner = 1;
     const int N = 93;
     std::vector<Variant> vs = {
-        VN("31x3 t64 192 lds w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        D("dma 31x3 t48 192 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 48, 192, TW_LDS, 3),
-        DS("split5 t32 640 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 32, 640, TW_LDS, 1),
-        DS("split5 t32 320 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 32, 320, TW_LDS, 1),
-        DS("split5 t32 256 w2 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 32, 256, TW_LDS, 2),
-        DS("split3 t32 384 w1 nt2", 3, 2, float, 93, 2, 31, 3, 1, 1, 32, 384, TW_LDS, 1),
-        DS("split3 t32 192 w2 nt2", 3, 2, float, 93, 2, 31, 3, 1, 1, 32, 192, TW_LDS, 2),
-        DS("split5 t64 960 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 64, 960, TW_LDS, 1),
-        DS("split5 t64 512 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 64, 512, TW_LDS, 1),
-        DS("split5 t42 640 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 42, 640, TW_LDS, 1),
-        DS("split8 t32 1024 w1 nt2", 8, 2, float, 93, 2, 31, 3, 1, 1, 32, 1024, TW_LDS, 1),
-        DS("split5 t32 640 w1 nt0", 5, 0, float, 93, 2, 31, 3, 1, 1, 32, 640, TW_LDS, 1),
-        DS("split5 t20 384 w1 nt2", 5, 2, float, 93, 2, 31, 3, 1, 1, 20, 384, TW_LDS, 1),
+        VN("31x3 t64 192 w3 nt2 pad0", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VNP("31x3 t64 192 w3 nt2 pad6", 2, 6, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VNP("31x3 t64 192 w3 nt2 pad3", 2, 3, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VNP("31x3 t64 192 w3 nt2 pad1", 2, 1, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VNP("31x3 t64 192 w3 nt2 pad2", 2, 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VNP("31x3 t64 192 w3 nt2 pad4", 2, 4, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VNP("31x3 t64 192 w3 nt2 pad7", 2, 7, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VNP("31x3 t64 192 w3 nt0 pad6", 0, 6, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VNP("3x31 t64 192 w3 nt2 pad6", 2, 6, float, 93, 2, 3, 31, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VNP("31x3 t60 192 w3 nt2 pad6", 2, 6, float, 93, 2, 31, 3, 1, 1, 60, 192, false, false, false, TW_LDS, 3, false),
     };
 #elif GROUP == 3  // ---- 500k x 128 rows (config 1 shape, config 5 z axis) ----
     const long long batch = 500000, outer = 1, inner = 1;
