@@ -138,3 +138,24 @@ def test_streaming_twins_at_streaming_size(n):
         got = out[lo:lo + 5].double().cpu()
         assert ((got - ref).reshape(5, -1).norm(dim=1) / ref.reshape(5, -1).norm(dim=1)).max().item() < 1e-5
     assert not torch.isnan(out).any()
+
+
+def test_empty_batch_and_bad_slab_ranges():
+    ctx = mf.DeviceContext(0)
+    for shape in [(0, 1024, 2), (0, 64, 64, 2), (0, 1 << 17, 2)]:
+        x = torch.zeros(shape, device=DEV)
+        out = torch.zeros(shape, device=DEV)
+        plan = mf.plan_fft(torch.float32, torch.float32, shape, shape, ctx=ctx)
+        mf.fft(out, x, ctx, plan=plan)      # nothing to do, nothing launched, no error
+        ctx.synchronize()
+    x = torch.randn((6, 128, 2), device=DEV)
+    out = torch.full_like(x, float("nan"))
+    plan = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, ctx=ctx)
+    for first, count in [(-1, 2), (5, 2), (0, 7), (3, -1)]:
+        with pytest.raises(mf.MifftError) as e:
+            mf.fft(out, x, ctx, plan=plan, first=first, count=count)
+        assert e.value.status == -8
+    assert torch.isnan(out).all()
+    mf.fft(out, x, ctx, plan=plan, first=5, count=1)
+    ctx.synchronize()
+    assert torch.isnan(out[:5]).all() and not torch.isnan(out[5]).any()
