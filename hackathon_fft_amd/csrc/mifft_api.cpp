@@ -83,6 +83,24 @@ hipError_t upload_twiddle_table(int out_dtype, int64_t N, bool inverse, void** d
     return err;
 }
 
+// Switches to the plan's device for the duration of a call and restores the caller's current device
+// afterwards (the library must not leave a side effect on the host framework's device state).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 static int device_count_quiet() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -209,7 +227,8 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                          "libmifft has no CPU path: device " + std::to_string(device) + " is not a usable HIP device (" +
                              std::to_string(ndev) + " visible)");
     }
-    hipError_t e = hipSetDevice(device);
+    DeviceGuard guard(device);
+    hipError_t e = guard.err;
     if (e != hipSuccess) {
         delete h;
         return hip_error(e, "hipSetDevice");
@@ -302,7 +321,8 @@ int mifft_exec_batch(const mifft_plan* plan, const void* x, void* out, int64_t f
     // out-of-place contract (reference: first stage reads x, all writes go elsewhere)
     if (xb < ob + (size_t)count * out_row && ob < xb + (size_t)count * in_row)
         return set_error(MIFFT_ERR_ALIAS, "x and out must not overlap");
-    MIFFT_HIP_TRY(hipSetDevice(p.device));
+    DeviceGuard guard(p.device);
+    MIFFT_HIP_TRY(guard.err);
     hipStream_t s = (hipStream_t)stream;
     char* sb = p.d_scratch ? (char*)p.d_scratch + (size_t)first * out_row : nullptr;
     auto buf = [&](int which) -> char* { return which == 0 ? (char*)xb : which == 2 ? sb : ob; };
@@ -322,8 +342,10 @@ int mifft_exec(const mifft_plan* plan, const void* x, void* out, void* stream) {
 
 void mifft_plan_destroy(mifft_plan* plan) {
     if (!plan) return;
-    (void)hipSetDevice(plan->p.device);
-    free_plan_device(plan->p);
+    {
+        DeviceGuard guard(plan->p.device);
+        free_plan_device(plan->p);
+    }
     delete plan;
 }
 
@@ -358,7 +380,8 @@ size_t mifft_plan_out_bytes(const mifft_plan* plan) {
 int mifft_time_exec(const mifft_plan* plan, const void* x, void* out, void* stream, int iters, float* ms_out) {
     if (!plan || !ms_out) return set_error(MIFFT_ERR_NULL, "plan or ms_out is NULL");
     if (iters < 1) iters = 1;
-    MIFFT_HIP_TRY(hipSetDevice(plan->p.device));
+    DeviceGuard guard(plan->p.device);
+    MIFFT_HIP_TRY(guard.err);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t he = hipEventCreate(&e0);
