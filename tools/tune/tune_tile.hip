@@ -165,19 +165,22 @@ int main(int argc, char** argv) {
     const long long batch = 100000, outer = 1, inner = 1;
     const int N = 1024;
     std::vector<Variant> vs = {
-        VN("16x8x8 t4 reg w2 pf nt0", 0, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
-        VN("16x8x8 t4 reg w2 pf nt1", 1, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
-        VN("16x8x8 t4 reg w2 pf nt2", 2, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
-        VN("16x8x8 t4 reg w2 pf nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
-        VN("16x8x8 t4 lds w4 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
-        VN("16x8x8 t4 lds w3 pf nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 3, true),
-        VN("16x8x8 t4 lds w4 nt0", 0, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
-        VN("16x8x8 t2 lds w4 pf nt3", 3, float, 1024, 3, 16, 8, 8, 1, 2, 128, false, true, true, TW_LDS, 4, true),
-        VN("16x8x8 t1 reg w2 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 1, 64, false, true, true, TW_REG, 2, false),
-        VN("8x8x16 t4 reg w2 pf nt3", 3, float, 1024, 3, 8, 8, 16, 1, 4, 256, false, true, true, TW_REG, 2, true),
-        VN("8x16x8 t4 reg w2 pf nt3", 3, float, 1024, 3, 8, 16, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
-        VN("4x4x8x8 t2 reg w4 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_REG, 4, false),
-        VN("4x4x8x8 t4 lds w4 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x4x8x8 t4 512 lds w2 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x4x8x8 t4 512 lds w2 pf nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, true),
+        VN("4x4x8x8 t4 512 lds w4 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 4, false),
+        VN("4x4x8x8 t2 256 lds w4 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 4, false),
+        VN("4x4x8x8 t8 1024 lds w4 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 8, 1024, false, true, true, TW_LDS, 4, false),
+        VN("4x4x8x8 t4 512 reg w2 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_REG, 2, false),
+        VN("8x4x4x8 t4 512 lds w2 nt3", 3, float, 1024, 4, 8, 4, 4, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x8x4x8 t4 512 lds w2 nt3", 3, float, 1024, 4, 4, 8, 4, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("8x8x4x4 t4 512 lds w2 nt3", 3, float, 1024, 4, 8, 8, 4, 4, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x4x4x16 t4 512 lds w2 nt3", 3, float, 1024, 4, 4, 4, 4, 16, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("8x8x16 t4 512 lds w2 nt3", 3, float, 1024, 3, 8, 8, 16, 1, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x16x16 t4 512 lds w2 nt3", 3, float, 1024, 3, 4, 16, 16, 1, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("16x8x8 t4 256 lds w4 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VN("16x8x8 t4 256 reg w2 pf nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
+        VN("4x4x8x8 t4 512 lds w2 nt1", 1, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x4x8x8 t4 512 lds w2 nt0", 0, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
     };
 #elif GROUP == 2  // ---- config 3: 500k x 93 ----
     const long long batch = 500000, outer = 1, inner = 1;
