@@ -9,7 +9,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmifft.so")
+# MIFFT_LIBRARY points the loader at another build of the same library (A/B runs of kernel variants); it is still a
+# libmifft.so and still has to export every entry point.
+LIB_PATH = os.environ.get("MIFFT_LIBRARY") or os.path.join(_HERE, "csrc", "libmifft.so")
 
 # every entry point include/mifft.h declares
 EXPORTS = (

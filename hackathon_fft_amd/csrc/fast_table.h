@@ -17,6 +17,8 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
     tp.tw = pass.d_twiddle;
     tp.inverse = plan.inverse;
     tp.scale = plan.inverse ? 1.0 / (double)pass.N : 1.0;
+    tp.tlo = pass.d_aux;   // TSTORE configurations only
+    tp.thi = pass.d_aux2;
     if (C::COLS) {
         tp.inner = pass.inner;
         tp.tiles_per_outer = (pass.inner + C::TILE - 1) / C::TILE;
@@ -51,6 +53,7 @@ static int prepare_tile() {
 }
 
 struct FastEntry {
+    bool tstore;      // four-step first pass: transposed + twiddled store (needs pass.d_aux / d_aux2)
     bool in_real;     // the kernel promotes a real (C_in = 1) tensor in its pass-0 load
     int stream_pref;  // 1: only for streaming-size problems (non-temporal twin), -1: any size
     int out_dtype;
@@ -63,22 +66,24 @@ struct FastEntry {
     size_t lds;
 };
 
-#define MIFFT_CFG_X(REAL, NTM, STREAM, NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                         \
+#define MIFFT_CFG_X(TS, REAL, NTM, STREAM, NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                         \
     {                                                                                                               \
-        REAL, STREAM, DT, N, COLS, NAME, launch_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM>>,   \
-            prepare_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM>>, \
-            TILE, THREADS, TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM>::LDS_BYTES       \
+        TS, REAL, STREAM, DT, N, COLS, NAME, launch_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM, TS>>,   \
+            prepare_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM, TS>>, \
+            TILE, THREADS, TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM, TS>::LDS_BYTES       \
     }
 
 
-#define MIFFT_CFG(...) MIFFT_CFG_X(false, 0, -1, __VA_ARGS__)
+#define MIFFT_CFG(...) MIFFT_CFG_X(false, false, 0, -1, __VA_ARGS__)
 // complex-input kernel + its real-input twin (contiguous dimension only)
 #define MIFFT_CFG_CR(NAME, ...) \
-    MIFFT_CFG_X(false, 0, -1, NAME, __VA_ARGS__), MIFFT_CFG_X(true, 0, -1, NAME "_r", __VA_ARGS__)
+    MIFFT_CFG_X(false, false, 0, -1, NAME, __VA_ARGS__), MIFFT_CFG_X(false, true, 0, -1, NAME "_r", __VA_ARGS__)
 // non-temporal twin for problems that dwarf the Infinity Cache (listed BEFORE the plain entry)
-#define MIFFT_CFG_STREAM(NAME, ...) MIFFT_CFG_X(false, 3, 1, NAME "_nt", __VA_ARGS__)
+#define MIFFT_CFG_STREAM(NAME, ...) MIFFT_CFG_X(false, false, 3, 1, NAME "_nt", __VA_ARGS__)
 // ... with non-temporal stores only (tiles staged through a flat LDS copy re-read their lines)
-#define MIFFT_CFG_STREAM_ST(NAME, ...) MIFFT_CFG_X(false, 2, 1, NAME "_nts", __VA_ARGS__)
+#define MIFFT_CFG_STREAM_ST(NAME, ...) MIFFT_CFG_X(false, false, 2, 1, NAME "_nts", __VA_ARGS__)
+// column tile with the transposed + twiddled store (first pass of the four-step); pass LAST_DIRECT = false
+#define MIFFT_CFG_TS(NAME, ...) MIFFT_CFG_X(true, false, 0, -1, NAME "_ts", __VA_ARGS__)
 
 // tables instantiated in kernels_fast_gen_rows.hip / kernels_fast_gen_cols.hip (host-only data:
 // kept TU-local there so that the device pass never sees the host launcher pointers)
@@ -86,5 +91,7 @@ const FastEntry* gen_rows_table(int* count);
 const FastEntry* gen_cols_table(int* count);
 const FastEntry* gen_rows_f64_table(int* count);
 const FastEntry* gen_cols_f64_table(int* count);
+// column tile of length pass.N with the transposed + twiddled store, or false
+bool select_fast_tstore(const Plan& plan, DimPass& pass);
 
 }  // namespace mifft

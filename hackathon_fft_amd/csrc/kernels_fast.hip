@@ -38,6 +38,14 @@ static const FastEntry kFastTable[] = {
     // 16 columns x 1024 points = 128 KiB: the four-step passes of 2^20-point transforms (0.266 vs 0.349 ms for
     // the generated 8-column tile at 64 x 2^20)
     MIFFT_CFG("cols1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+    // transposed + twiddled stores: the first pass of the two-pass four-step (N = N1 * N2, N1 one of these)
+    MIFFT_CFG_TS("cols4096_8x8x8x8", float, MIFFT_F32, 4096, 4, 8, 8, 8, 8, 4, 512, true, true, false, TW_GLOBAL, 1, false),
+    MIFFT_CFG_TS("cols2048_8x16x16", float, MIFFT_F32, 2048, 3, 8, 16, 16, 1, 8, 512, true, true, false, TW_LDS, 1, false),
+    MIFFT_CFG_TS("cols1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 16, 512, true, true, false, TW_LDS, 1, false),
+    MIFFT_CFG_TS("cols512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 16, 512, true, true, false, TW_LDS, 1, false),
+    MIFFT_CFG_TS("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, false, TW_LDS, 2, false),
+    MIFFT_CFG_TS("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, false, TW_LDS, 4, false),
+    MIFFT_CFG_TS("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, false, TW_LDS, 4, false),
     MIFFT_CFG("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, true, TW_LDS, 2, false),
@@ -128,6 +136,21 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
     return false;
 }
 
+bool select_fast_tstore(const Plan& plan, DimPass& pass) {
+    for (const FastEntry& e : kFastTable) {
+        if (!e.tstore || e.out_dtype != plan.out_dtype || e.N != pass.N || pass.inner < e.tile) continue;
+        pass.kernel_name = e.name;
+        pass.launch = e.launch;
+        pass.prepare = e.prepare;
+        pass.tile = e.tile;
+        pass.threads = e.threads;
+        pass.lds_bytes = e.lds;
+        pass.ld = (int)pass.N;
+        return true;
+    }
+    return false;
+}
+
 bool select_fast(const Plan& plan, DimPass& pass) {
     // fast families read real or complex input of the output dtype; integer input and mixed
     // precision run on the generic family
@@ -136,7 +159,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
     // read + write volume of one exec far beyond the 256-MB Infinity Cache -> non-temporal twins apply
     const bool streaming = (double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0 > 0.6e9;
     auto try_entry = [&](const FastEntry& e) {
-        if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols) return false;
+        if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols || e.tstore) return false;
         if (e.in_real != (pass.first && plan.in_components == 1)) return false;
         if (e.stream_pref == 1 && !streaming) return false;
         if (cols && pass.inner < e.tile) return false;

@@ -11,8 +11,7 @@
 // both factors rounded once from long double (k1*n2 < N, so no modular reduction is needed).
 #include <cmath>
 
-#include "fft_radix.h"
-#include "mifft_internal.h"
+#include "fast_table.h"
 
 namespace mifft {
 
@@ -149,7 +148,12 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
         probe.passes.clear();
         const bool fa = make_cols_pass(probe, dim_index, n1, n2, a, w) && std::string(a.kernel_name) != "generic";
         const bool fb = make_cols_pass(probe, dim_index, n2, n1, b, w) && std::string(b.kernel_name) != "generic";
-        double score = std::fabs(std::log((double)n1 / (double)n2)) + (fa ? 0 : 4) + (fb ? 0 : 4);
+        DimPass ts;
+        ts.N = n1;
+        ts.inner = n2;
+        const bool two_pass = fb && select_fast_tstore(probe, ts);  // no middle pass, no scratch
+        double score = std::fabs(std::log((double)n1 / (double)n2)) + (fa || two_pass ? 0 : 4) + (fb ? 0 : 4) -
+                       (two_pass ? 3 : 0);
         if (score < best_score) {
             best_score = score;
             best1 = n1;
@@ -161,8 +165,38 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
         return false;
     }
     DimPass p1, p3, p2;
-    if (!make_cols_pass(plan, dim_index, best1, best2, p1, why_not)) return false;
     if (!make_cols_pass(plan, dim_index, best2, best1, p3, why_not)) return false;
+    // two-pass form: the first column pass stores transposed + twiddled straight into `out` (no scratch)
+    {
+        DimPass ts;
+        ts.dim_index = dim_index;
+        ts.N = best1;
+        ts.inner = best2;
+        ts.outer = 1;
+        ts.first = false;
+        if (select_fast_tstore(plan, ts)) {
+            ts.src_buf = 0;  // x
+            ts.dst_buf = 1;  // out
+            p3.src_buf = 1;
+            p3.dst_buf = 1;
+            if (ts.prepare && ts.prepare() != MIFFT_OK) return false;
+            if (p3.prepare && p3.prepare() != MIFFT_OK) return false;
+            const bool inv2 = plan.inverse != 0;
+            hipError_t e2 = upload_twiddle_table(plan.out_dtype, ts.N, inv2, &ts.d_twiddle);
+            if (e2 == hipSuccess) e2 = upload_twiddle_table(plan.out_dtype, p3.N, inv2, &p3.d_twiddle);
+            if (e2 == hipSuccess)
+                e2 = plan.out_dtype == MIFFT_F32 ? upload_two_level<float>(N, &ts.d_aux, &ts.d_aux2)
+                                                 : upload_two_level<double>(N, &ts.d_aux, &ts.d_aux2);
+            plan.passes.push_back(ts);
+            plan.passes.push_back(p3);
+            if (e2 != hipSuccess) {
+                why_not = std::string("device allocation: ") + hipGetErrorString(e2);
+                return false;
+            }
+            return true;
+        }
+    }
+    if (!make_cols_pass(plan, dim_index, best1, best2, p1, why_not)) return false;
     p1.src_buf = 0;  // x
     p1.dst_buf = 2;  // scratch
     p3.src_buf = 1;  // out, in place

@@ -75,6 +75,10 @@ struct TileParams {
     long long tiles_per_outer;  // COLS
     int inverse;
     double scale;  // 1/N for inverse
+    // TSTORE configurations (first pass of the four-step): two-level table of W_M^m, M = N * inner,
+    // W_M^m = tlo[m mod 1024] * thi[m div 1024]
+    const void* tlo;
+    const void* thi;
 };
 
 constexpr int ilog2_ce(int v) {
@@ -88,7 +92,7 @@ enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
 
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
-          bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0>
+          bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -125,7 +129,23 @@ struct TileCfg {
         return o;
     }
     static constexpr int TWL_TOTAL = TWMODE_ == TW_LDS ? TWL_OFF(NP_) : 0;
-    static constexpr int DATA_ELEMS = COLS_ ? N_ * TILE_ : LD * TILE_;
+    // TSTORE (column tiles only): the finished tile is stored TRANSPOSED and multiplied by the four-step twiddle
+    // W^{k1*n2}: columns c0..c0+TILE-1 of the [N][inner] matrix become TILE contiguous rows of the [inner][N]
+    // matrix, so the store is one flat coalesced run.  The LDS column pitch is TILE + 1 so that the transposed
+    // read (lanes along n) is conflict-free.
+    // Re-derive every thread-index-dependent offset inside each tile iteration instead of letting the compiler
+    // hoist them out of the persistent loop (see tile_kernel).  Column tiles and very long rows carry dozens of
+    // such offsets and spill or lose occupancy when they stay live; the short-row kernels run at copy speed with
+    // them hoisted and lose 3-8 % to the recomputation (A/B on MI355X, gpurun_out/ab_opaque.log).
+#ifdef MIFFT_OPAQUE_ROWS
+    static constexpr bool OPAQUE_TID = true;
+#else
+    static constexpr bool OPAQUE_TID = COLS_ || N_ >= 8192;
+#endif
+    static constexpr bool TSTORE = TSTORE_;
+    static constexpr int CPITCH = TSTORE_ ? TILE_ + 1 : TILE_;
+    static_assert(!TSTORE_ || (COLS_ && !LAST_DIRECT_ && FIRST_DIRECT_), "TSTORE: column tile, last pass left in LDS");
+    static constexpr int DATA_ELEMS = COLS_ ? N_ * CPITCH : LD * TILE_;
     // DMA: the flat HBM -> LDS copy of the NEXT tile runs asynchronously (global_load_lds) into a staging
     // buffer behind the twiddle table while this tile's passes execute
     static constexpr bool DMA = DMA_;
@@ -160,7 +180,7 @@ MIFFT_DEV int swz(int n) {
 template <class C, int E>
 MIFFT_DEV int lds_index(int c, int n) {
     if constexpr (C::COLS)
-        return n * C::TILE + c;
+        return n * C::CPITCH + c;
     else
         return c * C::LD + swz<C, E>(n);
 }
@@ -253,6 +273,14 @@ MIFFT_DEV void fill_lds_tw(cpx<typename C::T>* ltw, const cpx<typename C::T>* tw
     }
 }
 
+// Experiment switch: keep the butterflies of one thread apart in the instruction schedule (lower register pressure,
+// less ILP).  Off in the product build.
+#ifdef MIFFT_SCHED_FENCE
+#define MIFFT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MIFFT_FENCE() ((void)0)
+#endif
+
 // gather the pass-0 inputs of tile (base, nv) from HBM into registers
 template <class C>
 MIFFT_DEV void load_pass0(const TileParams& p, cpx<typename C::T> (*v)[C::R(0)], long long base, int nv, int tid) {
@@ -325,10 +353,15 @@ MIFFT_DEV void pass_gather_lds(const TileParams& p, const cpx<typename C::T>* sr
                         w = ((const V*)p.tw)[j * pp * RATIO];
                         if (p.inverse) w.y = -w.y;
                     }
+#ifndef MIFFT_ABLATE_MATH
                     v[k][j] = cmul(v[k][j], w);
+#else
+                    v[k][j].x += w.x;
+#endif
                 }
             }
         }
+        MIFFT_FENCE();
     }
 }
 
@@ -348,7 +381,9 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
         if (EXACT || id < C::ITEMS(I)) {
             int c, b;
             item_decode<C, I>(id, c, b);
+#ifndef MIFFT_ABLATE_MATH  // timing experiment only: data movement without butterflies / twiddles
             Dft<R, T, 1>::run(v[k]);
+#endif
             const int q = b / P, pp = b - q * P;
             const int o0 = q * P * R + pp;
             if constexpr (DST_GLOBAL) {
@@ -370,6 +405,7 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
                 for (int s = 0; s < R; ++s) lds[lds_index<C, I>(c, o0 + s * P)] = v[k][s];
             }
         }
+        MIFFT_FENCE();
     }
 }
 
@@ -416,11 +452,11 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
     using V = cpx<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     V* lds = (V*)smem;
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     V twr[(C::TWMODE == TW_REG && C::TW_TOTAL > 0) ? C::TW_TOTAL : 1];
-    if constexpr (C::TWMODE == TW_REG) preload_tw<C, 1>(twr, (const V*)p.tw, tid, p.inverse);
+    if constexpr (C::TWMODE == TW_REG) preload_tw<C, 1>(twr, (const V*)p.tw, tid0, p.inverse);
     if constexpr (C::TWMODE == TW_LDS) {
-        fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, tid, p.inverse);
+        fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, tid0, p.inverse);
         __syncthreads();
     }
 
@@ -431,10 +467,19 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             long long base;
             int nv;
             tile_geom<C>(p, t, base, nv);
-            load_pass0<C>(p, pre, base, nv, tid);
+            load_pass0<C>(p, pre, base, nv, tid0);
         }
     }
+    const int tid_entry = tid0;
     for (; t < p.n_tiles; t += gridDim.x) {
+        // The thread index is made opaque once per tile: every LDS / twiddle / HBM offset derived from it is then
+        // recomputed inside the iteration (a few dozen VALU operations) instead of being hoisted out of the
+        // persistent loop, where dozens of loop-invariant address registers stay live across the whole tile and
+        // push the kernel over its VGPR budget.
+        int tid = tid_entry;
+#ifndef MIFFT_NO_OPAQUE_TID
+        if constexpr (C::OPAQUE_TID) asm volatile("" : "+v"(tid));
+#endif
         long long base;
         int nv;
         tile_geom<C>(p, t, base, nv);
@@ -470,7 +515,26 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             __syncthreads();
         }
         run_pass<C, 0>(p, lds, twr, cur, base, nv, tid);
-        if constexpr (!C::LAST_DIRECT) {
+        if constexpr (C::TSTORE) {
+            // transposed + twiddled flat store: out[o][c0 + c][k1] = tile[k1][c] * W^{k1 * (c0 + c)}
+            const long long o = t / p.tiles_per_outer;
+            const long long c0 = (t - o * p.tiles_per_outer) * C::TILE;
+            V* gout = (V*)p.out + o * (long long)C::N * p.inner + c0 * (long long)C::N;
+            const V* tlo = (const V*)p.tlo;
+            const V* thi = (const V*)p.thi;
+            const int total = nv * C::N;
+            for (int f = tid; f < total; f += C::THREADS) {
+                const int c = f / C::N, k1 = f - c * C::N;
+                const long long m = (long long)k1 * (c0 + c);  // < N * inner
+                V y = cmul(lds[k1 * C::CPITCH + c], cmul(tlo[m & 1023], thi[m >> 10]));
+                if (p.inverse) {  // conj(F(conj x)) * conj(W) * 1/N = conj(F(conj x) * W) * 1/N
+                    y.x *= (T)p.scale;
+                    y.y *= -(T)p.scale;
+                }
+                gstore<(C::NT & 2) != 0>(gout + f, y);
+            }
+            __syncthreads();
+        } else if constexpr (!C::LAST_DIRECT) {
             static_assert(!C::COLS || C::LAST_DIRECT, "column tiles always store directly");
             V* gout = (V*)p.out;
             const int total = nv * C::N;

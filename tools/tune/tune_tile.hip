@@ -225,6 +225,13 @@ int main(int argc, char** argv) {
         V("c640 8x8x10 t16 512 lds", float, 640, 3, 8, 8, 10, 1, 16, 512, true, true, true, TW_LDS, 1, false),
         V("c640 4x4x8x5 t16 768 lds", float, 640, 4, 4, 4, 8, 5, 16, 768, true, true, true, TW_LDS, 1, false),
         V("c640 4x4x8x5 t16 640 lds", float, 640, 4, 4, 4, 8, 5, 16, 640, true, true, true, TW_LDS, 1, false),
+        V("c640 10x8x8 t16 512 glb w4", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_GLOBAL, 4, false),
+        V("c640 8x8x10 t16 512 glb w4", float, 640, 3, 8, 8, 10, 1, 16, 512, true, true, true, TW_GLOBAL, 4, false),
+        V("c640 4x4x8x5 t16 512 glb w4", float, 640, 4, 4, 4, 8, 5, 16, 512, true, true, true, TW_GLOBAL, 4, false),
+        V("c640 5x8x4x4 t16 512 glb w4", float, 640, 4, 5, 8, 4, 4, 16, 512, true, true, true, TW_GLOBAL, 4, false),
+        V("c640 10x8x8 t16 512 glb w2", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_GLOBAL, 2, false),
+        V("c640 4x4x8x5 t16 1024 glb w4", float, 640, 4, 4, 4, 8, 5, 16, 1024, true, true, true, TW_GLOBAL, 4, false),
+        V("c640 10x8x8 t16 1024 glb w4", float, 640, 3, 10, 8, 8, 1, 16, 1024, true, true, true, TW_GLOBAL, 4, false),
     };
 #elif GROUP == 5  // ---- config 4 first pass: 64000 rows of 480 ----
     const long long batch = 64000, outer = 1, inner = 1;
@@ -269,6 +276,11 @@ int main(int argc, char** argv) {
         V("c1024 16x8x8 t8 256 lds w2", float, 1024, 3, 16, 8, 8, 1, 8, 256, true, true, true, TW_LDS, 2, false),
         V("c1024 4x4x8x8 t8 256 lds w2", float, 1024, 4, 4, 4, 8, 8, 8, 256, true, true, true, TW_LDS, 2, false),
         V("c1024 4x4x8x8 t4 256 lds w2", float, 1024, 4, 4, 4, 8, 8, 4, 256, true, true, true, TW_LDS, 2, false),
+        V("c1024 16x8x8 t16 1024 lds pf", float, 1024, 3, 16, 8, 8, 1, 16, 1024, true, true, true, TW_LDS, 1, true),
+        V("c1024 4x4x8x8 t16 1024 lds pf", float, 1024, 4, 4, 4, 8, 8, 16, 1024, true, true, true, TW_LDS, 1, true),
+        V("c1024 8x8x16 t16 1024 lds pf", float, 1024, 3, 8, 8, 16, 1, 16, 1024, true, true, true, TW_LDS, 1, true),
+        V("c1024 16x8x8 t16 512 lds pf", float, 1024, 3, 16, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        V("c1024 16x8x8 t16 1024 glob pf", float, 1024, 3, 16, 8, 8, 1, 16, 1024, true, true, true, TW_GLOBAL, 1, true),
     };
 #elif GROUP == 9  // ---- rows of 256, 400k transforms ----
     const long long batch = 400000, outer = 1, inner = 1;
