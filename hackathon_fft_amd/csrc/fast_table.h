@@ -19,6 +19,7 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
     tp.scale = plan.inverse ? 1.0 / (double)pass.N : 1.0;
     tp.tlo = pass.d_aux;   // TSTORE configurations only
     tp.thi = pass.d_aux2;
+    tp.tcol = pass.d_aux3;
     if (C::COLS) {
         tp.inner = pass.inner;
         tp.tiles_per_outer = (pass.inner + C::TILE - 1) / C::TILE;

@@ -108,16 +108,21 @@ struct PlaneEntry {
     size_t lds;
 };
 
-// rows configuration (N2, TILE = N1, HBM -> LDS) then columns configuration (N1, TILE = N2, LDS -> HBM)
-// (a 128 x 128 plane = 128 KiB fits LDS but leaves ONE workgroup per CU, which cannot overlap its HBM
-//  and LDS phases: measured 0.121 ms for z+y of 10 x 128^3 against 0.060 + 0.061 ms for the two
-//  separate passes -- tools/tune/tune_tile.hip GROUP 7 -- so 128^3 keeps three passes.)
-using Plane64R = TileCfg<float, 64, 3, 4, 4, 4, 1, 64, 512, false, true, false, TW_LDS, 2, true>;
-using Plane64C = TileCfg<float, 64, 3, 4, 4, 4, 1, 64, 512, true, false, true, TW_LDS, 2, false>;
+// rows configuration (N2, TILE = N1, HBM -> LDS) then columns configuration (N1, TILE = N2, LDS -> HBM).
+// A 128 x 128 plane = 128 KiB leaves ONE workgroup per CU: it pays only with the next plane prefetched into
+// registers and with per-plane recomputed offsets (tile_kernel.h, OPAQUE_TID) -- before that change the same kernel
+// spilled and took 0.121 ms for z+y of 10 x 128^3 against 0.060 + 0.061 ms for the two separate passes; now
+// 0.080 ms (tools/tune/tune_tile.hip GROUP 7).
+using Plane64R = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false>;
+using Plane64C = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, true, false, true, TW_LDS, 2, false>;
+using Plane128R = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true>;
+using Plane128C = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false>;
 
 static const PlaneEntry kPlaneTable[] = {
-    {MIFFT_F32, 64, 64, "plane64x64_4x4x4", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>, 512,
+    {MIFFT_F32, 64, 64, "plane64x64_8x8", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>, 512,
      Plane64R::LDS_BYTES},
+    {MIFFT_F32, 128, 128, "plane128x128_16x8", launch_plane<Plane128R, Plane128C>, prepare_plane<Plane128R, Plane128C>,
+     1024, Plane128R::LDS_BYTES},
 };
 
 bool select_fast_plane(const Plan& plan, DimPass& pass) {

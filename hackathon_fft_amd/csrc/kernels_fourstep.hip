@@ -111,6 +111,22 @@ static hipError_t upload_two_level(int64_t N, void** d_lo, void** d_hi) {
     return e;
 }
 
+// [tile][n1] table of W_N^(c * k1): the twiddle of column c0 + c of a TSTORE tile relative to column c0
+template <typename T>
+static hipError_t upload_col_table(int64_t N, int64_t n1, int tile, void** d_tab) {
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    std::vector<T> tab(2 * (size_t)tile * (size_t)n1);
+    for (int c = 0; c < tile; ++c)
+        for (int64_t k1 = 0; k1 < n1; ++k1) {
+            long double th = -two_pi * (long double)((int64_t)c * k1) / (long double)N;
+            tab[2 * ((size_t)c * n1 + k1)] = (T)cosl(th);
+            tab[2 * ((size_t)c * n1 + k1) + 1] = (T)sinl(th);
+        }
+    hipError_t e = hipMalloc(d_tab, tab.size() * sizeof(T));
+    if (e == hipSuccess) e = hipMemcpy(*d_tab, tab.data(), tab.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
 // one column-tile pass of length n with element stride `inner`: fused table first, literal-stage fallback
 static bool make_cols_pass(const Plan& plan, int dim_index, int64_t n, int64_t inner, DimPass& ps, std::string& why) {
     ps = DimPass();
@@ -187,6 +203,9 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
             if (e2 == hipSuccess)
                 e2 = plan.out_dtype == MIFFT_F32 ? upload_two_level<float>(N, &ts.d_aux, &ts.d_aux2)
                                                  : upload_two_level<double>(N, &ts.d_aux, &ts.d_aux2);
+            if (e2 == hipSuccess)
+                e2 = plan.out_dtype == MIFFT_F32 ? upload_col_table<float>(N, ts.N, ts.tile, &ts.d_aux3)
+                                                 : upload_col_table<double>(N, ts.N, ts.tile, &ts.d_aux3);
             plan.passes.push_back(ts);
             plan.passes.push_back(p3);
             if (e2 != hipSuccess) {

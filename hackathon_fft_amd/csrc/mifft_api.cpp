@@ -61,7 +61,8 @@ static void free_plan_device(Plan& p) {
         if (ps.d_twiddle) (void)hipFree(ps.d_twiddle);
         if (ps.d_aux) (void)hipFree(ps.d_aux);
         if (ps.d_aux2) (void)hipFree(ps.d_aux2);
-        ps.d_twiddle = ps.d_aux = ps.d_aux2 = nullptr;
+        if (ps.d_aux3) (void)hipFree(ps.d_aux3);
+        ps.d_twiddle = ps.d_aux = ps.d_aux2 = ps.d_aux3 = nullptr;
     }
     if (p.d_scratch) (void)hipFree(p.d_scratch);
     p.d_scratch = nullptr;

@@ -65,6 +65,7 @@ struct DimPass {
     int src_buf = -1, dst_buf = -1;
     int64_t fs_n1 = 0, fs_n2 = 0;  // four-step factors of the dimension (transpose + twiddle pass)
     void* d_aux2 = nullptr;
+    void* d_aux3 = nullptr;           // TSTORE passes: [tile][N] table of W^(c*k1) for the columns of one tile
 };
 
 struct Plan {

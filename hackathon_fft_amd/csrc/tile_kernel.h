@@ -79,6 +79,7 @@ struct TileParams {
     // W_M^m = tlo[m mod 1024] * thi[m div 1024]
     const void* tlo;
     const void* thi;
+    const void* tcol;  // [TILE][N]: W_M^(c * k1), the twiddle of column c0 + c relative to column c0
 };
 
 constexpr int ilog2_ce(int v) {
@@ -522,16 +523,82 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             V* gout = (V*)p.out + o * (long long)C::N * p.inner + c0 * (long long)C::N;
             const V* tlo = (const V*)p.tlo;
             const V* thi = (const V*)p.thi;
-            const int total = nv * C::N;
-            for (int f = tid; f < total; f += C::THREADS) {
-                const int c = f / C::N, k1 = f - c * C::N;
-                const long long m = (long long)k1 * (c0 + c);  // < N * inner
-                V y = cmul(lds[k1 * C::CPITCH + c], cmul(tlo[m & 1023], thi[m >> 10]));
-                if (p.inverse) {  // conj(F(conj x)) * conj(W) * 1/N = conj(F(conj x) * W) * 1/N
-                    y.x *= (T)p.scale;
-                    y.y *= -(T)p.scale;
+            if constexpr (C::N % C::THREADS == 0 || C::THREADS % C::N == 0) {
+                // a thread keeps its k1 for the whole tile: W^(k1 * (c0 + c)) = W^(k1 * c0) [two-level lookup, once
+                // per k1] * W^(k1 * c) [plan-time table, read contiguously along k1]
+                constexpr int KPT = C::N >= C::THREADS ? C::N / C::THREADS : 1;
+                constexpr int CSTEP = C::N >= C::THREADS ? 1 : C::THREADS / C::N;
+                const int k1b = C::N >= C::THREADS ? tid : tid % C::N;
+                const int cb = C::N >= C::THREADS ? 0 : tid / C::N;
+                const V* tcol = (const V*)p.tcol;
+                V a[KPT];
+#pragma unroll
+                for (int kk = 0; kk < KPT; ++kk) {
+                    const long long m0 = (long long)(k1b + kk * C::THREADS) * c0;  // < N * inner
+                    a[kk] = cmul(tlo[m0 & 1023], thi[m0 >> 10]);
                 }
-                gstore<(C::NT & 2) != 0>(gout + f, y);
+                // all table reads of the tile are issued before the first use (the table is L2-resident)
+                constexpr int CIT = (C::TILE + CSTEP - 1) / CSTEP;
+                V w[CIT][KPT];
+                if constexpr (CSTEP == 1 && C::TILE % 4 == 0) {
+                    // only rows 1, 2, 3 and 4, 8, 12, ... of the table are read:
+                    // W^(k1 * (c0 + 4 q + r)) = [W^(k1 * c0) * W^(k1 * 4 q)] * W^(k1 * r)
+                    constexpr int Q = C::TILE / 4;
+                    V lo[3][KPT], hi[Q][KPT];
+#pragma unroll
+                    for (int kk = 0; kk < KPT; ++kk) {
+                        const int k1 = k1b + kk * C::THREADS;
+#pragma unroll
+                        for (int r = 1; r < 4; ++r) lo[r - 1][kk] = tcol[r * C::N + k1];
+#pragma unroll
+                        for (int q = 1; q < Q; ++q) hi[q][kk] = tcol[4 * q * C::N + k1];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < KPT; ++kk) {
+                        hi[0][kk] = a[kk];
+#pragma unroll
+                        for (int q = 1; q < Q; ++q) hi[q][kk] = cmul(a[kk], hi[q][kk]);
+#pragma unroll
+                        for (int i = 0; i < CIT; ++i)
+                            w[i][kk] = (i % 4 == 0) ? hi[i / 4][kk] : cmul(hi[i / 4][kk], lo[i % 4 - 1][kk]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < CIT; ++i) {
+                        const int c = cb + i * CSTEP;
+                        const int cc = c < C::TILE ? c : C::TILE - 1;
+#pragma unroll
+                        for (int kk = 0; kk < KPT; ++kk) w[i][kk] = cmul(a[kk], tcol[cc * C::N + k1b + kk * C::THREADS]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < CIT; ++i) {
+                    const int c = cb + i * CSTEP;
+                    if (c < nv) {
+#pragma unroll
+                        for (int kk = 0; kk < KPT; ++kk) {
+                            const int k1 = k1b + kk * C::THREADS;
+                            V y = cmul(lds[k1 * C::CPITCH + c], w[i][kk]);
+                            if (p.inverse) {  // conj(F(conj x)) * conj(W) * 1/N = conj(F(conj x) * W) * 1/N
+                                y.x *= (T)p.scale;
+                                y.y *= -(T)p.scale;
+                            }
+                            gstore<(C::NT & 2) != 0>(gout + c * C::N + k1, y);
+                        }
+                    }
+                }
+            } else {
+                const int total = nv * C::N;
+                for (int f = tid; f < total; f += C::THREADS) {
+                    const int c = f / C::N, k1 = f - c * C::N;
+                    const long long m = (long long)k1 * (c0 + c);  // < N * inner
+                    V y = cmul(lds[k1 * C::CPITCH + c], cmul(tlo[m & 1023], thi[m >> 10]));
+                    if (p.inverse) {
+                        y.x *= (T)p.scale;
+                        y.y *= -(T)p.scale;
+                    }
+                    gstore<(C::NT & 2) != 0>(gout + f, y);
+                }
             }
             __syncthreads();
         } else if constexpr (!C::LAST_DIRECT) {
@@ -767,18 +834,23 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
                   "square planes with one shared LDS twiddle table");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     V* lds = (V*)smem;
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     V twr[1];
-    fill_lds_tw<CR, 1>(lds + CR::DATA_ELEMS, (const V*)p.tw, tid, p.inverse);
+    fill_lds_tw<CR, 1>(lds + CR::DATA_ELEMS, (const V*)p.tw, tid0, p.inverse);
     __syncthreads();
 
     constexpr long long PLANE = (long long)CR::N * CR::TILE;
     V pre[CR::PREFETCH ? CR::IPT(0) : 1][CR::R(0)];
     long long t = blockIdx.x;
     if constexpr (CR::PREFETCH) {
-        if (t < p.n_tiles) load_pass0<CR>(p, pre, t * PLANE, CR::TILE, tid);
+        if (t < p.n_tiles) load_pass0<CR>(p, pre, t * PLANE, CR::TILE, tid0);
     }
+    const int tid_entry = tid0;
     for (; t < p.n_tiles; t += gridDim.x) {
+        int tid = tid_entry;  // opaque per plane: see tile_kernel
+#ifndef MIFFT_NO_OPAQUE_TID
+        asm volatile("" : "+v"(tid));
+#endif
         const long long base = t * PLANE;
         V cur[CR::PREFETCH ? CR::IPT(0) : 1][CR::R(0)];
         if constexpr (CR::PREFETCH) {

@@ -92,6 +92,8 @@ BASELINE_CASES = [
     ((2, 128, 128, 128), None),
     ((3, 64, 64, 64), None),     # fused 64x64 LDS plane + in-place column tiles
     ((70, 64, 64), None),        # 2-D through the fused plane kernel alone
+    ((7, 128, 128), None),       # fused 128x128 plane (one workgroup per CU, next plane prefetched)
+    ((300, 128, 128), None),     # more planes than workgroups: the persistent loop + prefetch path
     ((2, 256, 256), None),
     ((3, 512), None),
     ((3, 2048), None),

@@ -155,6 +155,10 @@ Variant make_plane(const char* name) {
     make_plane<TileCfg<float, 128, NP, R0, R1, R2, R3, 128, THR, false, true, false, TW_LDS, MINW, PF>,          \
                TileCfg<float, 128, NP, R0, R1, R2, R3, 128, THR, true, false, true, TW_LDS, MINW, false>>(NAME)
 
+#define PLN(NAME, PN, THR, MINW, PF, R0, R1, R2, R3, NP)                                                         \
+    make_plane<TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, false, true, false, TW_LDS, MINW, PF>,            \
+               TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, true, false, true, TW_LDS, MINW, false>>(NAME)
+
 int main(int argc, char** argv) {
     if (argc > 1) g_wg_override = atoi(argv[1]);
     hipDeviceProp_t prop;
@@ -354,13 +358,33 @@ int main(int argc, char** argv) {
         PL("plane 4x4x8 1024 w4", 1024, 4, false, 4, 4, 8, 1, 3),
         PL("plane 4x4x8 512 w2 pf", 512, 2, true, 4, 4, 8, 1, 3),
         PL("plane 8x4x4 256 w1 pf", 256, 1, true, 8, 4, 4, 1, 3),
+        PL("plane 16x8 1024 w4 pf", 1024, 4, true, 16, 8, 1, 1, 2),
+        PL("plane 8x16 1024 w4", 1024, 4, false, 8, 16, 1, 1, 2),
+        PL("plane 8x16 1024 w4 pf", 1024, 4, true, 8, 16, 1, 1, 2),
+    };
+#elif GROUP == 13  // ---- 100 x 64^3: fused y+x planes, 6400 planes of 64x64 ----
+    const long long batch = 100, outer = 64, inner = 1;
+    const int N = 64;
+    std::vector<Variant> vs = {
+        PLN("plane64 4x4x4 512 w2 pf", 64, 512, 2, true, 4, 4, 4, 1, 3),
+        PLN("plane64 4x4x4 512 w2", 64, 512, 2, false, 4, 4, 4, 1, 3),
+        PLN("plane64 4x4x4 256 w2 pf", 64, 256, 2, true, 4, 4, 4, 1, 3),
+        PLN("plane64 4x4x4 256 w4", 64, 256, 4, false, 4, 4, 4, 1, 3),
+        PLN("plane64 8x8 512 w2", 64, 512, 2, false, 8, 8, 1, 1, 2),
+        PLN("plane64 8x8 512 w2 pf", 64, 512, 2, true, 8, 8, 1, 1, 2),
+        PLN("plane64 8x8 256 w2", 64, 256, 2, false, 8, 8, 1, 1, 2),
+        PLN("plane64 8x8 256 w2 pf", 64, 256, 2, true, 8, 8, 1, 1, 2),
+        PLN("plane64 8x8 256 w4", 64, 256, 4, false, 8, 8, 1, 1, 2),
+        PLN("plane64 16x4 256 w2", 64, 256, 2, false, 16, 4, 1, 1, 2),
+        PLN("plane64 4x16 256 w2", 64, 256, 2, false, 4, 16, 1, 1, 2),
+        PLN("plane64 8x8 1024 w4", 64, 1024, 4, false, 8, 8, 1, 1, 2),
     };
 #else
 #error "define GROUP"
 #endif
 
-#if GROUP == 7
-    const size_t elems = (size_t)batch * outer * 128 * 128;
+#if GROUP == 7 || GROUP == 13
+    const size_t elems = (size_t)batch * outer * N * N;
 #else
     const size_t elems = (size_t)batch * outer * inner * N;
 #endif
