@@ -28,8 +28,8 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_CR("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
     // one 128-KiB row per workgroup; twiddles from the global table (the compact LDS table would need 131 KB more)
     MIFFT_CFG("rows16384_16x16x8x8", float, MIFFT_F32, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, false),
-    MIFFT_CFG_STREAM_ST("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-    MIFFT_CFG_CR("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+    MIFFT_CFG_STREAM_ST("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+    MIFFT_CFG_CR("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
     MIFFT_CFG_CR("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_CR("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     // ---- strided dimensions, fp32 (in place, LDS column tiles) ----
@@ -56,7 +56,7 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_CR("rows256_f64_4x8x8", double, MIFFT_F64, 256, 3, 4, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows128_f64_8x4x4", double, MIFFT_F64, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows64_f64_4x4x4", double, MIFFT_F64, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_LDS, 1, false),
-    MIFFT_CFG_CR("rows93_f64_31x3", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 32, 96, false, false, false, TW_LDS, 1, false),
+    MIFFT_CFG_CR("rows93_f64_31x3", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 32, 96, false, true, false, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows480_f64_10x6x8", double, MIFFT_F64, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows640_f64_10x8x8", double, MIFFT_F64, 640, 3, 10, 8, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG("cols640_f64_4x4x8x5", double, MIFFT_F64, 640, 4, 4, 4, 8, 5, 8, 256, true, true, true, TW_LDS, 1, false),

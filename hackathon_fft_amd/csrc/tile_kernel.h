@@ -503,15 +503,17 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             static_assert(!C::COLS || C::FIRST_DIRECT, "column tiles always load directly");
             const V* gin = (const V*)p.in;
             const int total = nv * C::N;
-            for (int f = tid; f < total; f += C::THREADS) {
-                const int c = f / C::N, n = f - c * C::N;
-                V x = {(T)0, (T)0};
-                if constexpr (C::IN_REAL)
-                    x.x = gload_real<(C::NT & 1) != 0>((const T*)p.in + base + f);
-                else
-                    x = gload<(C::NT & 1) != 0>(gin + base + f);
-                if (p.inverse) x.y = -x.y;
-                lds[lds_index<C, -1>(c, n)] = x;
+            {
+                for (int f = tid; f < total; f += C::THREADS) {
+                    const int c = f / C::N, n = f - c * C::N;
+                    V x = {(T)0, (T)0};
+                    if constexpr (C::IN_REAL)
+                        x.x = gload_real<(C::NT & 1) != 0>((const T*)p.in + base + f);
+                    else
+                        x = gload<(C::NT & 1) != 0>(gin + base + f);
+                    if (p.inverse) x.y = -x.y;
+                    lds[lds_index<C, -1>(c, n)] = x;
+                }
             }
             __syncthreads();
         }
@@ -619,198 +621,6 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// tile_kernel_dma<C>: the flat-copy configurations (rows that are not 16-byte aligned, e.g. N = 93)
-// with an asynchronous HBM -> LDS copy.  While the passes of tile t run in the work buffer, the
-// rows of tile t+1 stream into a staging buffer by LDS-DMA (global_load_lds_dwordx4: per-lane
-// source address, LDS destination = wave-uniform base + lane*16, no VGPRs), so the workgroup
-// always has a whole tile of HBM reads in flight.  Pass 0 reads the staging buffer and scatters
-// into the work buffer; the copy of the next tile is issued as soon as every wave has gathered.
-// Requires a 16-byte aligned tile base (checked by the launcher; otherwise tile_kernel<C> runs).
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* mifft_lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* mifft_glb_ptr_t;
-
-template <class C>
-MIFFT_DEV void dma_issue_tile(const TileParams& p, cpx<typename C::T>* stage, long long base, int nv, int tid) {
-    using V = cpx<typename C::T>;
-    constexpr int PER16 = 16 / (int)sizeof(V);            // complex elements per 16-byte piece
-    const int pieces = (nv * C::N) / PER16;               // launcher guarantees nv*N*sizeof(V) % 16 == 0
-    const char* g = (const char*)((const V*)p.in + base);
-    const int lane = tid & 63, wave0 = tid - lane;  // first thread of this wave (the last wave may be partial)
-    for (int w0 = wave0; w0 < pieces; w0 += C::THREADS) {
-        const int idx = w0 + lane;
-        if (idx < pieces)
-            __builtin_amdgcn_global_load_lds((mifft_glb_ptr_t)(g + (size_t)idx * 16),
-                                             (mifft_lds_ptr_t)((char*)stage + (size_t)w0 * 16), 16, 0, 0);
-    }
-    // odd element count (a ragged last tile of odd-length rows): the trailing 8 bytes go the ordinary way
-    if (PER16 == 2 && ((nv * C::N) & 1) && tid == 0) stage[nv * C::N - 1] = ((const V*)p.in)[base + nv * C::N - 1];
-}
-
-template <class C>
-__global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel_dma(const TileParams p) {
-    using T = typename C::T;
-    using V = cpx<T>;
-    static_assert(C::DMA && !C::COLS && !C::FIRST_DIRECT && !C::LAST_DIRECT && !C::IN_REAL && C::LD == C::N,
-                  "DMA staging is for the flat-copy row configurations");
-    static_assert(C::TWMODE != TW_REG, "register twiddles not wired for the DMA variant");
-    // Two DISTINCT LDS objects: the module-LDS lowering gives each its own alias scope, which lets the
-    // waitcnt pass see that LDS writes into the work buffer do not touch the DMA destination -- with one
-    // (dynamic) LDS array it put s_waitcnt vmcnt(0) in front of the first ds_write after the DMA issue.
-    __shared__ __attribute__((aligned(16))) V s_work[C::DATA_ELEMS + (C::TWL_TOTAL > 0 ? C::TWL_TOTAL : 1)];
-    __shared__ __attribute__((aligned(16))) V s_stage[C::STAGE_ELEMS];
-    V* lds = s_work;
-    V* stage = s_stage;
-    const int tid = threadIdx.x;
-    V twr[1];
-    if constexpr (C::TWMODE == TW_LDS) fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, tid, p.inverse);
-
-    long long t = blockIdx.x;
-    if (t < p.n_tiles) {
-        long long base;
-        int nv;
-        tile_geom<C>(p, t, base, nv);
-        dma_issue_tile<C>(p, stage, base, nv, tid);
-    }
-    for (; t < p.n_tiles; t += gridDim.x) {
-        long long base;
-        int nv;
-        tile_geom<C>(p, t, base, nv);
-        // this wave's share of the copy has landed (and its previous stores have drained) ...
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wg_barrier<C>();  // ... and so has every other wave's; nobody still reads the work buffer
-        constexpr int R0 = C::R(0), IPT0 = C::IPT(0);
-        V v[IPT0][R0];
-        pass_gather_lds<C, 0>(p, stage, lds + C::DATA_ELEMS, twr, v, tid);
-        if (p.inverse) {
-#pragma unroll
-            for (int k = 0; k < IPT0; ++k)
-#pragma unroll
-                for (int j = 0; j < R0; ++j) v[k][j].y = -v[k][j].y;
-        }
-        wg_barrier<C>();  // staging buffer fully consumed
-        const long long tn = t + gridDim.x;
-        if (tn < p.n_tiles) {
-            long long nbase;
-            int nnv;
-            tile_geom<C>(p, tn, nbase, nnv);
-            dma_issue_tile<C>(p, stage, nbase, nnv, tid);  // overlaps with everything below
-        }
-        pass_compute_scatter<C, 0>(p, lds, v, base, nv, tid);
-        wg_barrier<C>();
-        V none[1][R0];
-        run_pass<C, 1>(p, lds, twr, none, base, nv, tid);
-        // flat coalesced LDS -> HBM store of the finished tile
-        V* gout = (V*)p.out;
-        const int total = nv * C::N;
-        for (int f = tid; f < total; f += C::THREADS) {
-            V y = lds[f];  // last exchange is natural order, LD == N
-            if (p.inverse) {
-                y.x *= (T)p.scale;
-                y.y *= -(T)p.scale;
-            }
-            gstore<(C::NT & 2) != 0>(gout + base + f, y);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// tile_kernel_dma_split<C, G>: tile_kernel_dma with an OUTPUT-SPLIT prime pass 0.  A row of 93 = 31 * 3
-// points has only three 31-point butterflies, each ~170 live VGPRs: too few, too fat work items to hide
-// their latency (with a free butterfly the DMA kernel reaches 0.131 ms at 500k x 93, with the real one
-// 0.167 ms).  Here G lanes share one butterfly: lane group g reads the 31 staged inputs, forms the
-// conjugate sums and computes only its own output pairs, writing each to the work buffer at once.
-// Slots are laid out [g][padded item] with the pad a multiple of 64, so g is wave-uniform and its
-// constants stay compile-time.
-// ---------------------------------------------------------------------------------------------
-template <class C, int G, int g0, class X, class Emit>
-MIFFT_DEV void prime_group_dispatch(int g, const X* x, Emit& emit) {
-    if constexpr (g0 < G) {
-        if (g == g0)
-            PrimeGroup<C::R(0), typename C::T, G, g0>::run(x, emit);
-        else
-            prime_group_dispatch<C, G, g0 + 1>(g, x, emit);
-    }
-}
-
-template <class C, int G>
-__global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel_dma_split(const TileParams p) {
-    using T = typename C::T;
-    using V = cpx<T>;
-    static_assert(C::DMA && !C::COLS && !C::FIRST_DIRECT && !C::LAST_DIRECT && !C::IN_REAL && C::LD == C::N,
-                  "DMA staging is for the flat-copy row configurations");
-    static_assert(C::TWMODE != TW_REG && is_prime_ce(C::R(0)) && C::R(0) > 2 && C::THREADS % 64 == 0, "split prime pass 0");
-    __shared__ __attribute__((aligned(16))) V s_work[C::DATA_ELEMS + (C::TWL_TOTAL > 0 ? C::TWL_TOTAL : 1)];
-    __shared__ __attribute__((aligned(16))) V s_stage[C::STAGE_ELEMS];
-    V* lds = s_work;
-    V* stage = s_stage;
-    const int tid = threadIdx.x;
-    V twr[1];
-    if constexpr (C::TWMODE == TW_LDS) fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, tid, p.inverse);
-
-    constexpr int R0 = C::R(0), NB0 = C::NB(0);
-    constexpr int PER_G = NB0 * C::TILE, PAD = (PER_G + 63) / 64 * 64, SLOTS = PAD * G;
-    constexpr int ROUNDS = (SLOTS + C::THREADS - 1) / C::THREADS;
-
-    long long t = blockIdx.x;
-    if (t < p.n_tiles) {
-        long long base;
-        int nv;
-        tile_geom<C>(p, t, base, nv);
-        dma_issue_tile<C>(p, stage, base, nv, tid);
-    }
-    for (; t < p.n_tiles; t += gridDim.x) {
-        long long base;
-        int nv;
-        tile_geom<C>(p, t, base, nv);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wg_barrier<C>();
-        // ---- pass 0: staged rows -> G lanes per prime butterfly -> work buffer ----
-#pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) {
-            const int id = tid + k * C::THREADS;
-            if (SLOTS % C::THREADS == 0 || id < SLOTS) {
-                const int g = __builtin_amdgcn_readfirstlane(id / PAD);  // PAD and THREADS are multiples of 64
-                const int r = id - g * PAD;
-                if (r < PER_G) {
-                    const int c = r / NB0, b = r - c * NB0;
-                    V x[R0];
-#pragma unroll
-                    for (int j = 0; j < R0; ++j) x[j] = stage[c * C::N + b + j * NB0];
-                    if (p.inverse) {
-#pragma unroll
-                        for (int j = 0; j < R0; ++j) x[j].y = -x[j].y;
-                    }
-                    V* row = lds + c * C::LD;
-                    auto emit = [&](int s, V val) { row[swz<C, 0>(b * R0 + s)] = val; };  // P = 1: position q*R + s
-                    prime_group_dispatch<C, G, 0>(g, x, emit);
-                }
-            }
-        }
-        wg_barrier<C>();  // staging buffer consumed, work buffer holds pass-0 output
-        const long long tn = t + gridDim.x;
-        if (tn < p.n_tiles) {
-            long long nbase;
-            int nnv;
-            tile_geom<C>(p, tn, nbase, nnv);
-            dma_issue_tile<C>(p, stage, nbase, nnv, tid);
-        }
-        V none[1][R0];
-        run_pass<C, 1>(p, lds, twr, none, base, nv, tid);
-        V* gout = (V*)p.out;
-        const int total = nv * C::N;
-        for (int f = tid; f < total; f += C::THREADS) {
-            V y = lds[f];
-            if (p.inverse) {
-                y.x *= (T)p.scale;
-                y.y *= -(T)p.scale;
-            }
-            gstore<(C::NT & 2) != 0>(gout + base + f, y);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // plane_kernel<CR, CC>: the two innermost dimensions (N1 x N2, N2 contiguous) of one 2-D slice are

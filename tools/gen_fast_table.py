@@ -90,7 +90,9 @@ def row_cfg(n, f64=False):
             return None  # 16 elements/thread needs 1024 threads = 128 VGPRs: spills
         tile = 1
         threads = min(512, pow2ceil(n // (8 if f64 else 16)))
-    fd = (n // f[0]) >= 16
+    # pass 0 reads HBM directly even when a butterfly's lanes cover only a few consecutive elements: N = 93 (runs of
+    # 3 elements) gained 15 % over the flat LDS staging copy (tools/tune GROUP 2)
+    fd = os.environ.get("MIFFT_GEN_FD", "1") == "1" or (n // f[0]) >= 16
     ld = (n // f[-1]) >= 16
     return f, tile, threads, fd, ld
 

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../hackathon_fft_amd/csrc/tile_kernel.h"
+#include "tile_kernel_experimental.h"
 
 using namespace mifft;
 
@@ -190,16 +191,18 @@ int main(int argc, char** argv) {
     const long long batch = 500000, outer = 1, inner = 1;
     const int N = 93;
     std::vector<Variant> vs = {
-        VN("31x3 t64 192 w3 nt2 pad0", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VNP("31x3 t64 192 w3 nt2 pad6", 2, 6, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VNP("31x3 t64 192 w3 nt2 pad3", 2, 3, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VNP("31x3 t64 192 w3 nt2 pad1", 2, 1, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VNP("31x3 t64 192 w3 nt2 pad2", 2, 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VNP("31x3 t64 192 w3 nt2 pad4", 2, 4, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VNP("31x3 t64 192 w3 nt2 pad7", 2, 7, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VNP("31x3 t64 192 w3 nt0 pad6", 0, 6, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VNP("3x31 t64 192 w3 nt2 pad6", 2, 6, float, 93, 2, 3, 31, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
-        VNP("31x3 t60 192 w3 nt2 pad6", 2, 6, float, 93, 2, 31, 3, 1, 1, 60, 192, false, false, false, TW_LDS, 3, false),
+        VN("31x3 t64 192 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VN("31x3 t64 192 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t64 192 w3 nt3 fd", 3, float, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t64 192 w3 nt0 fd", 0, float, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t64 192 w2 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 2, false),
+        VN("31x3 t64 192 w2 nt2 fd pf", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 2, true),
+        VN("31x3 t32 96 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 32, 96, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t128 384 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 128, 384, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t21 63 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 21, 63, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t42 126 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 42, 126, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t64 192 w3 nt2 fd reg", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_REG, 3, false),
+        VN("31x3 t85 255 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 85, 255, false, true, false, TW_LDS, 3, false),
     };
 #elif GROUP == 3  // ---- 500k x 128 rows (config 1 shape, config 5 z axis) ----
     const long long batch = 500000, outer = 1, inner = 1;
