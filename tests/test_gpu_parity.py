@@ -290,7 +290,8 @@ def test_full_size_properties(shape, bases):
 @pytest.mark.parametrize("n,batch,dtype", [(32768, 3, np.float32), (65536, 2, np.float32), (1 << 20, 1, np.float32),
                                            (100000, 3, np.float32), (98304, 2, np.float32), (20480, 5, np.float32),
                                            (50000, 2, np.float64), (1 << 17, 1, np.float64), (1 << 22, 1, np.float32),
-                                           (1 << 24, 1, np.float32), (40960, 3, np.float32), (1 << 23, 2, np.float32)])
+                                           (1 << 24, 1, np.float32), (40960, 3, np.float32), (1 << 23, 2, np.float32),
+                                           (16384, 260, np.float32)])   # big batch of LDS-sized rows: two passes preferred
 def test_four_step_large_dimension(n, batch, dtype):
     """Dimensions beyond one workgroup's LDS row: column FFTs with a transposed + twiddled
     store, then column FFTs in place (two launches, no scratch) when the first factor has such a kernel; otherwise

@@ -90,6 +90,12 @@ def row_cfg(n, f64=False):
             return None  # 16 elements/thread needs 1024 threads = 128 VGPRs: spills
         tile = 1
         threads = min(512, pow2ceil(n // (8 if f64 else 16)))
+        if not f64 and n >= 6144:
+            # one 48-64-KiB row + an equally large twiddle table per workgroup = one workgroup per CU: 1024 threads
+            # and the next row prefetched into registers (8192 points: 0.137 -> 0.122 ms, tools/tune GROUP 14)
+            fd = (n // f[0]) >= 16
+            ld = (n // f[-1]) >= 16
+            return f, tile, 1024, fd, ld, True
     # pass 0 reads HBM directly even when a butterfly's lanes cover only a few consecutive elements: N = 93 (runs of
     # 3 elements) gained 15 % over the flat LDS staging copy (tools/tune GROUP 2)
     fd = os.environ.get("MIFFT_GEN_FD", "1") == "1" or (n // f[0]) >= 16
@@ -141,7 +147,7 @@ def col_cfg(n, f64=False):
     return f, tile, threads
 
 
-def emit(name, n, f, tile, threads, cols, fd, ld, f64=False):
+def emit(name, n, f, tile, threads, cols, fd, ld, f64=False, pf=False):
     r = list(f) + [1] * (4 - len(f))
     rs = "x".join(str(v) for v in f)
     ty, dt, suffix = ("double", "MIFFT_F64", "_f64") if f64 else ("float", "MIFFT_F32", "")
@@ -150,7 +156,7 @@ def emit(name, n, f, tile, threads, cols, fd, ld, f64=False):
     twm = "TW_LDS" if (n * tile + twl_entries(f)) * esz <= 156 * 1024 else "TW_GLOBAL"
     return (f'    MIFFT_CFG("{name}{n}{suffix}_{rs}", {ty}, {dt}, {n}, {len(f)}, {r[0]}, {r[1]}, {r[2]}, {r[3]}, '
             f'{tile}, {threads}, {"true" if cols else "false"}, {"true" if fd else "false"}, '
-            f'{"true" if ld else "false"}, {twm}, 1, false),')
+            f'{"true" if ld else "false"}, {twm}, 1, {"true" if pf else "false"}),')
 
 
 HAND_ROWS_F64 = {1024, 512, 256, 128, 64, 93, 480, 640}
@@ -164,7 +170,7 @@ def main():
         if n not in HAND_ROWS:
             c = row_cfg(n)
             if c:
-                rows.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4]))
+                rows.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], pf=len(c) > 5 and c[5]))
         if n not in HAND_COLS and n <= 8192:
             c = col_cfg(n)
             if c:

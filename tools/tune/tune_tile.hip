@@ -382,6 +382,33 @@ int main(int argc, char** argv) {
         PLN("plane64 4x16 256 w2", 64, 256, 2, false, 4, 16, 1, 1, 2),
         PLN("plane64 8x8 1024 w4", 64, 1024, 4, false, 8, 8, 1, 1, 2),
     };
+#elif GROUP == 14  // ---- long rows: 3906 x 8192 ----
+    const long long batch = 3906, outer = 1, inner = 1;
+    const int N = 8192;
+    std::vector<Variant> vs = {
+        V("r8192 16x8x8x8 512 lds", float, 8192, 4, 16, 8, 8, 8, 1, 512, false, true, true, TW_LDS, 1, false),
+        V("r8192 16x8x8x8 512 lds pf", float, 8192, 4, 16, 8, 8, 8, 1, 512, false, true, true, TW_LDS, 1, true),
+        V("r8192 16x8x8x8 512 lds w2 pf", float, 8192, 4, 16, 8, 8, 8, 1, 512, false, true, true, TW_LDS, 2, true),
+        V("r8192 8x8x8x16 512 lds pf", float, 8192, 4, 8, 8, 8, 16, 1, 512, false, true, true, TW_LDS, 1, true),
+        V("r8192 16x8x8x8 1024 lds", float, 8192, 4, 16, 8, 8, 8, 1, 1024, false, true, true, TW_LDS, 1, false),
+        V("r8192 16x8x8x8 1024 lds pf", float, 8192, 4, 16, 8, 8, 8, 1, 1024, false, true, true, TW_LDS, 1, true),
+        V("r8192 16x8x8x8 256 lds w2", float, 8192, 4, 16, 8, 8, 8, 1, 256, false, true, true, TW_LDS, 2, false),
+        V("r8192 16x8x8x8 512 glb w2", float, 8192, 4, 16, 8, 8, 8, 1, 512, false, true, true, TW_GLOBAL, 2, false),
+        V("r8192 16x8x8x8 512 glb w2 pf", float, 8192, 4, 16, 8, 8, 8, 1, 512, false, true, true, TW_GLOBAL, 2, true),
+        VN("r8192 16x8x8x8 512 lds pf nt3", 3, float, 8192, 4, 16, 8, 8, 8, 1, 512, false, true, true, TW_LDS, 1, true),
+    };
+#elif GROUP == 15  // ---- long rows: 1953 x 16384 ----
+    const long long batch = 1953, outer = 1, inner = 1;
+    const int N = 16384;
+    std::vector<Variant> vs = {
+        V("r16384 16x16x8x8 1024 glb w4", float, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, false),
+        V("r16384 16x16x8x8 1024 glb w4 pf", float, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, true),
+        V("r16384 8x8x16x16 1024 glb w4 pf", float, 16384, 4, 8, 8, 16, 16, 1, 1024, false, true, true, TW_GLOBAL, 4, true),
+        V("r16384 16x16x8x8 512 glb w2", float, 16384, 4, 16, 16, 8, 8, 1, 512, false, true, true, TW_GLOBAL, 2, false),
+        V("r16384 16x16x8x8 512 glb w2 pf", float, 16384, 4, 16, 16, 8, 8, 1, 512, false, true, true, TW_GLOBAL, 2, true),
+        V("r16384 16x16x16x4 1024 glb w4 pf", float, 16384, 4, 16, 16, 16, 4, 1, 1024, false, true, true, TW_GLOBAL, 4, true),
+        VN("r16384 16x16x8x8 1024 glb w4 pf nt3", 3, float, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, true),
+    };
 #else
 #error "define GROUP"
 #endif
