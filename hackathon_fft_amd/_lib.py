@@ -18,7 +18,7 @@ EXPORTS = (
     "mifft_plan_create", "mifft_exec", "mifft_exec_batch", "mifft_plan_destroy", "mifft_plan_stages",
     "mifft_plan_kernel_name", "mifft_plan_num_launches", "mifft_plan_in_bytes", "mifft_plan_out_bytes",
     "mifft_ordered_bases", "mifft_estimate_bases", "mifft_last_error", "mifft_status_string",
-    "mifft_version", "mifft_device_count", "mifft_time_exec",
+    "mifft_version", "mifft_device_count", "mifft_time_exec", "mifft_jit_precompile",
 )
 
 
@@ -69,6 +69,7 @@ def lib() -> ctypes.CDLL:
     L.mifft_status_string.argtypes = [c.c_int]
     L.mifft_status_string.restype = c.c_char_p
     L.mifft_time_exec.argtypes = [vp, vp, vp, vp, c.c_int, c.POINTER(c.c_float)]
+    L.mifft_jit_precompile.argtypes = [c.c_int, i64, c.c_int, c.c_int, c.POINTER(c.c_size_t)]
     _lib = L
     return L
 

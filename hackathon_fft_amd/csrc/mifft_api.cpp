@@ -298,6 +298,12 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                 }
             }
             if (!ok) ok = select_fast(p, ps);
+            // no table entry: specialise the tile kernel for this length now (strided dimensions up to 4096 points;
+            // longer ones are better off on the transposed route below)
+            if (!ok && (ps.inner == 1 || ps.N <= 4096)) {
+                std::string whyj;
+                ok = select_jit(p, ps, whyj);
+            }
             // long strided dimension without a fused column tile: transposes + the contiguous-row kernel beat the
             // literal-stage column fallback by an order of magnitude (and lift its 10 240-point limit)
             if (!ok && ps.inner != 1 && ps.N > 4096) {
@@ -429,6 +435,15 @@ int mifft_time_exec(const mifft_plan* plan, const void* x, void* out, void* stre
     if (rc) return rc;
     if (he != hipSuccess) return hip_error(he, "mifft_time_exec events");
     *ms_out = ms / (float)iters;
+    return MIFFT_OK;
+}
+
+int mifft_jit_precompile(int out_dtype, int64_t length, int strided, int real_input, size_t* code_bytes_out) {
+    if (out_dtype != MIFFT_F32 && out_dtype != MIFFT_F64) return set_error(MIFFT_ERR_BAD_DTYPE, "out dtype must be f32 or f64");
+    if (length < 2) return set_error(MIFFT_ERR_BAD_DIM, "length must be >= 2");
+    std::string why;
+    const int rc = jit_precompile(out_dtype, length, strided, real_input, code_bytes_out, why);
+    if (rc != MIFFT_OK) return set_error(rc, why);
     return MIFFT_OK;
 }
 

@@ -65,6 +65,7 @@ struct DimPass {
     int src_buf = -1, dst_buf = -1;
     int64_t fs_n1 = 0, fs_n2 = 0;  // four-step factors of the dimension (transpose + twiddle pass)
     void* d_aux2 = nullptr;
+    void* jit_fn = nullptr;           // runtime-compiled kernel (hipFunction_t) of kernels_jit.cpp passes
     void* d_aux3 = nullptr;           // TSTORE passes: [tile][N] table of W^(c*k1) for the columns of one tile
 };
 
@@ -92,6 +93,9 @@ struct Plan {
 // accepts the (plan, pass) pair.
 bool select_generic(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_fast(const Plan& plan, DimPass& pass);
+// the tile kernel specialised at plan time with hipRTC for a length without a table entry (kernels_jit.cpp)
+bool select_jit(const Plan& plan, DimPass& pass, std::string& why_not);
+int jit_precompile(int out_dtype, int64_t n, int cols, int in_real, size_t* code_bytes, std::string& why);
 // fused pass over the two innermost dimensions (pass.N = contiguous dim, pass.N1 = the next one)
 bool select_fast_plane(const Plan& plan, DimPass& pass);
 // a contiguous dimension too long for one workgroup: three passes (column FFTs of N1, transpose + twiddle,

@@ -451,7 +451,11 @@ template <class C>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TileParams p) {
     using T = typename C::T;
     using V = cpx<T>;
+#ifdef MIFFT_STATIC_LDS  // runtime-compiled instances (kernels_jit.cpp): no per-function dynamic-LDS opt-in needed
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
+#else
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
     V* lds = (V*)smem;
     const int tid0 = threadIdx.x;
     V twr[(C::TWMODE == TW_REG && C::TW_TOTAL > 0) ? C::TW_TOTAL : 1];

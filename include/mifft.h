@@ -178,6 +178,18 @@ int mifft_device_count(void);             /* usable HIP devices, 0 if none */
 int mifft_time_exec(const mifft_plan* plan, const void* x, void* out, void* stream, int iters,
                     float* ms_out);
 
+/*
+ * mifft_jit_precompile -- build (do not load) the runtime-specialised fused kernel that plan creation would use for
+ * a dimension of `length` points without a precompiled table entry, and report the size of its gfx950 code object.
+ * The reference compiles every shape at build time (shapes are Mojo comptime parameters, fft/fft/fft.mojo:123-135);
+ * libmifft specialises its tile kernel with hipRTC on first use and caches the result per process.  Needs no
+ * device: usable to warm the cache ahead of plan creation or to check a length on a build machine.
+ * out_dtype: MIFFT_F32 / MIFFT_F64; strided != 0: the in-place column-tile form; real_input != 0: the C_in = 1 twin.
+ * Returns MIFFT_OK, or MIFFT_ERR_TOO_LARGE when the length has no fused configuration (a prime factor above 31,
+ * or a tile beyond the 160 KiB of LDS) -- such lengths run on the literal-stage kernels.
+ */
+int mifft_jit_precompile(int out_dtype, int64_t length, int strided, int real_input, size_t* code_bytes_out);
+
 #ifdef __cplusplus
 }
 #endif

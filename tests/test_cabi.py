@@ -92,3 +92,19 @@ def test_python_layout_checks_mirror_reference():
         mf.estimate_best_bases_nd((4, 1, 8, 2), (4, 1, 8, 2))  # inner dim of size 1
     assert mf.estimate_best_bases_nd((10, 640, 480, 2), (10, 640, 480, 2)) == [
         [5, 2, 2, 2, 2, 2, 2, 2], [5, 3, 2, 2, 2, 2, 2]]
+
+
+def test_jit_precompile_needs_no_device():
+    """hipRTC builds the runtime-specialised kernel on a machine without a GPU (the code object is only loaded at
+    plan creation); a prime factor above 31 has no fused configuration."""
+    import ctypes
+    from hackathon_fft_amd import _lib
+    L = _lib.lib()
+    sz = ctypes.c_size_t(0)
+    assert L.mifft_jit_precompile(0, 49, 0, 0, ctypes.byref(sz)) == 0
+    assert sz.value > 4096
+    assert L.mifft_jit_precompile(0, 77, 1, 0, ctypes.byref(sz)) == 0      # strided form
+    assert L.mifft_jit_precompile(1, 121, 0, 0, ctypes.byref(sz)) == 0     # fp64
+    assert L.mifft_jit_precompile(0, 97, 0, 0, ctypes.byref(sz)) == -9
+    assert b"fused" in L.mifft_last_error()
+    assert L.mifft_jit_precompile(5, 49, 0, 0, ctypes.byref(sz)) == -4

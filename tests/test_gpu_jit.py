@@ -1,0 +1,108 @@
+"""Runtime-specialised tile kernels (hackathon_fft_amd/csrc/kernels_jit.cpp): lengths without a precompiled table
+entry get the same fused kernel template, compiled with hipRTC at plan creation.  Checked against the oracle (small
+lengths) and fp64 pocketfft, contiguous and strided, fp32 / fp64, real input, inverse round trips, ragged batches."""
+import numpy as np
+import pytest
+import torch
+
+import hackathon_fft_amd as mf
+from conftest import REL_L2_TOL_F32, REL_L2_TOL_F64, from_complex, rel_l2, to_complex
+from oracle import mifft_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(x_np, out_dtype=None, inverse=False, bases=None):
+    x = torch.from_numpy(x_np).to("cuda:0")
+    odt = x.dtype if out_dtype is None else out_dtype
+    out = torch.full(tuple(x.shape[:-1]) + (2,), float("nan"), device="cuda:0", dtype=odt)
+    ctx = mf.DeviceContext(0)
+    plan = mf.plan_fft(x.dtype, odt, x.shape, out.shape, bases=bases, inverse=inverse, ctx=ctx)
+    mf.fft(out, x, ctx, plan=plan)
+    ctx.synchronize()
+    return out.cpu().numpy(), plan
+
+
+# 7^2, 11^2, 7^3, 7*11, primes as one pass, 11^3, 3*11*31, 2*3*5*7*11, 13^2, 17^2, 31^2, 29*31, 3^8, 23*4, 19*27
+JIT_ROWS = [49, 121, 343, 77, 31, 7, 13, 1331, 1023, 2310, 169, 289, 961, 899, 6561, 92, 513]
+
+
+@pytest.mark.parametrize("n", JIT_ROWS)
+def test_rows_fp32(n):
+    rng = np.random.default_rng(n)
+    batch = 131 if n <= 512 else 9
+    x = rng.standard_normal((batch, n, 2)).astype(np.float32)
+    out, plan = _run(x)
+    assert plan.kernel_name(0).endswith("_jit"), plan.kernel_name(0)
+    assert not np.isnan(out).any()
+    truth = np.fft.fft(to_complex(x), axis=1)
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32, plan.kernel_name(0)
+    if n <= 1400:   # the oracle (the reference's literal stages) in seconds
+        assert rel_l2(out, O.fftn(x)) < REL_L2_TOL_F32
+    back, _ = _run(out, inverse=True)
+    assert rel_l2(back, x) < REL_L2_TOL_F32
+
+
+@pytest.mark.parametrize("n,inner", [(49, 40), (121, 33), (77, 16), (343, 20), (31, 64), (1331, 17), (169, 48)])
+def test_cols_fp32(n, inner):
+    rng = np.random.default_rng(n + inner)
+    x = rng.standard_normal((3, n, inner, 2)).astype(np.float32)
+    out, plan = _run(x)
+    assert plan.kernel_name(0).endswith("_jit"), plan.kernel_name(0)
+    truth = np.fft.fftn(to_complex(x), axes=(1, 2))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
+    back, _ = _run(out, inverse=True)
+    assert rel_l2(back, x) < REL_L2_TOL_F32
+
+
+@pytest.mark.parametrize("n", [49, 121, 343, 847, 31])
+def test_rows_fp64(n):
+    rng = np.random.default_rng(n + 7)
+    x = rng.standard_normal((67, n, 2))
+    out, plan = _run(x)
+    assert plan.kernel_name(0).endswith("_jit"), plan.kernel_name(0)
+    assert rel_l2(out, O.fftn(x)) < REL_L2_TOL_F64
+    back, _ = _run(out, inverse=True)
+    assert rel_l2(back, x) < REL_L2_TOL_F64
+
+
+@pytest.mark.parametrize("n", [49, 363])
+def test_real_input_twin(n):
+    rng = np.random.default_rng(n + 11)
+    x = rng.standard_normal((45, n, 1)).astype(np.float32)
+    out, plan = _run(x)
+    assert plan.kernel_name(0).endswith("_r_jit"), plan.kernel_name(0)
+    truth = np.fft.fft(x[..., 0].astype(np.float64), axis=1)
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
+
+
+def test_mixed_nd_with_a_jit_dimension():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 49, 12, 121, 2)).astype(np.float32)
+    out, plan = _run(x)
+    names = [plan.kernel_name(d) for d in range(3)]
+    assert names[0].endswith("_jit") and names[2].endswith("_jit"), names
+    truth = np.fft.fftn(to_complex(x), axes=(1, 2, 3))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
+
+
+def test_results_do_not_depend_on_the_tile_slot_jit():
+    rng = np.random.default_rng(23)
+    one = rng.standard_normal((1, 343, 2)).astype(np.float32)
+    x = np.repeat(one, 70, axis=0)
+    out, _ = _run(x)
+    for i in range(1, 70):
+        assert np.array_equal(out[i], out[0]), i
+
+
+def test_lengths_outside_the_jit_stay_on_the_literal_stages(monkeypatch):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((5, 97, 2)).astype(np.float32)    # prime > 31
+    out, plan = _run(x)
+    assert plan.kernel_name(0) == "generic"
+    assert rel_l2(out, O.fftn(x)) < REL_L2_TOL_F32
+    x8 = rng.integers(0, 255, size=(5, 49, 2)).astype(np.uint8)   # integer input: generic family
+    xt = torch.from_numpy(x8).to("cuda:0")
+    o = torch.empty((5, 49, 2), device="cuda:0")
+    p = mf.plan_fft(torch.uint8, torch.float32, xt.shape, o.shape)
+    assert p.kernel_name(0) == "generic"
