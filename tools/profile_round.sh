@@ -4,12 +4,13 @@
 #   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (TCC slots), plus the same two
 #      passes over tools/micro/copy_shapes, whose float2 row kernel moves a KNOWN byte count in the
 #      same access pattern (calibration of the gfx950 FETCH_SIZE under-count).
-# Raw output lands in gpurun_out/prof_<tag>/; tools/summarize_prof.py condenses it into profiles/.
+# Raw output lands in gpurun_out/prof_<tag>_<workload>/; tools/summarize_prof.py condenses it into profiles/.
 set -o pipefail
 tag=${1:-r01}
 wl=${2:-1d_100kx1024_radix2}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/prof_$tag
+out=$root/gpurun_out/prof_${tag}_$wl
+rm -rf $out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --workload $wl --steps 100 --warmup 20 --no-cpu-baseline > $out/trace.log 2>&1 || { echo "trace failed"; tail -5 $out/trace.log; exit 1; }
@@ -17,4 +18,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 $root/bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $out/pmc_$c.log 2>&1 || { echo "pmc $c failed"; tail -5 $out/pmc_$c.log; exit 1; }
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/cal_$c -- $root/tools/micro/copy_shapes > $out/cal_$c.log 2>&1 || { echo "cal $c failed"; tail -5 $out/cal_$c.log; exit 1; }
 done
-find $out -name "*.csv" | head -30
+ls $out

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag>/ (rocprofv3 CSVs) into profiles/<tag>_<workload>.json + .md.
+"""Condense gpurun_out/prof_<tag>_<workload>/ (rocprofv3 CSVs) into profiles/<tag>_<workload>.json + .md.
 
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from
 separate passes, are in KiB, and FETCH_SIZE under-counts wide coalesced reads on gfx950 -- the
@@ -15,7 +15,7 @@ from collections import defaultdict
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 wl = sys.argv[2] if len(sys.argv) > 2 else "1d_100kx1024_radix2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+src = os.path.join(root, "gpurun_out", f"prof_{tag}_{wl}")
 
 
 def short(name):
