@@ -69,7 +69,7 @@ def lib() -> ctypes.CDLL:
     L.mifft_status_string.argtypes = [c.c_int]
     L.mifft_status_string.restype = c.c_char_p
     L.mifft_time_exec.argtypes = [vp, vp, vp, vp, c.c_int, c.POINTER(c.c_float)]
-    L.mifft_jit_precompile.argtypes = [c.c_int, i64, c.c_int, c.c_int, c.POINTER(c.c_size_t)]
+    L.mifft_jit_precompile.argtypes = [c.c_int, c.c_int, i64, c.c_int, c.c_int, c.POINTER(c.c_size_t)]
     _lib = L
     return L
 

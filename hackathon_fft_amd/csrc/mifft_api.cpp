@@ -438,11 +438,13 @@ int mifft_time_exec(const mifft_plan* plan, const void* x, void* out, void* stre
     return MIFFT_OK;
 }
 
-int mifft_jit_precompile(int out_dtype, int64_t length, int strided, int real_input, size_t* code_bytes_out) {
+int mifft_jit_precompile(int in_dtype, int out_dtype, int64_t length, int strided, int real_input,
+                         size_t* code_bytes_out) {
+    if (dtype_size(in_dtype) == 0) return set_error(MIFFT_ERR_BAD_DTYPE, "unknown in dtype");
     if (out_dtype != MIFFT_F32 && out_dtype != MIFFT_F64) return set_error(MIFFT_ERR_BAD_DTYPE, "out dtype must be f32 or f64");
     if (length < 2) return set_error(MIFFT_ERR_BAD_DIM, "length must be >= 2");
     std::string why;
-    const int rc = jit_precompile(out_dtype, length, strided, real_input, code_bytes_out, why);
+    const int rc = jit_precompile(in_dtype, out_dtype, length, strided, real_input, code_bytes_out, why);
     if (rc != MIFFT_OK) return set_error(rc, why);
     return MIFFT_OK;
 }

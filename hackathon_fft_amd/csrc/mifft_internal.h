@@ -95,7 +95,7 @@ bool select_generic(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_fast(const Plan& plan, DimPass& pass);
 // the tile kernel specialised at plan time with hipRTC for a length without a table entry (kernels_jit.cpp)
 bool select_jit(const Plan& plan, DimPass& pass, std::string& why_not);
-int jit_precompile(int out_dtype, int64_t n, int cols, int in_real, size_t* code_bytes, std::string& why);
+int jit_precompile(int in_dtype, int out_dtype, int64_t n, int cols, int in_real, size_t* code_bytes, std::string& why);
 // fused pass over the two innermost dimensions (pass.N = contiguous dim, pass.N1 = the next one)
 bool select_fast_plane(const Plan& plan, DimPass& pass);
 // a contiguous dimension too long for one workgroup: three passes (column FFTs of N1, transpose + twiddle,

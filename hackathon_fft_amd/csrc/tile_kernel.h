@@ -65,6 +65,25 @@ MIFFT_DEV void gstore(cpx<T>* p, cpx<T> v) {
     }
 }
 
+template <class A, class B> struct same_t { static constexpr bool value = false; };
+template <class A> struct same_t<A, A> { static constexpr bool value = true; };
+
+// one input element of a FOREIGN element type IT (uint8 / int32 / float under a double plan), real or interleaved
+// complex, widened to cpx<T>
+template <class C>
+MIFFT_DEV cpx<typename C::T> load_foreign(const void* in, long long idx) {
+    using T = typename C::T;
+    using IT = typename C::IT;
+    const IT* p = (const IT*)in;
+    if constexpr (C::IN_REAL) {
+        return {(T)p[idx], (T)0};
+    } else {
+        struct alignas(2 * sizeof(IT)) pair_t { IT re, im; };
+        const pair_t v = ((const pair_t*)p)[idx];
+        return {(T)v.re, (T)v.im};
+    }
+}
+
 struct TileParams {
     const void* in;
     void* out;
@@ -93,7 +112,7 @@ enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
 
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
-          bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false>
+          bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false, typename IT_ = T_>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -102,6 +121,10 @@ struct TileCfg {
     // pass 0 reads a REAL tensor (C_in = 1) and promotes it (fft/fft/_fft.mojo:254-255).  Compile-time:
     // a runtime switch inside the prefetching load loop cost 0.30 -> 0.49 ms at 100k x 1024.
     static constexpr bool IN_REAL = IN_REAL_;
+    // element type of the tensor pass 0 reads (the plan's in_dtype): T itself, or uint8 / int32 / float widened to T
+    // in the load (the reference's `x.load(...).cast[out_dtype]`, fft/fft/_fft.mojo:243-251).  Only the
+    // runtime-specialised kernels (kernels_jit.cpp) instantiate foreign input types.
+    using IT = IT_;
     // non-temporal HBM accesses (bit 0: loads, bit 1: stores).  A tile is read once and written once; the
     // streaming hint lifts a row-shaped copy from ~5.85 to ~6.4 TB/s on MI355X (tools/micro/copy_nt.hip) when
     // the tensors dwarf the 256-MB Infinity Cache, and HURTS cache-resident or in-place passes (measured:
@@ -304,7 +327,9 @@ MIFFT_DEV void load_pass0(const TileParams& p, cpx<typename C::T> (*v)[C::R(0)],
             const long long step = (long long)NB * elem_stride<C>(p);  // uniform: element j sits j*step further
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                if constexpr (C::IN_REAL) {
+                if constexpr (!same_t<typename C::IT, T>::value) {
+                    v[k][j] = load_foreign<C>(p.in, base + j * step + off);
+                } else if constexpr (C::IN_REAL) {
                     v[k][j].x = gload_real<(C::NT & 1) != 0>((const T*)p.in + base + j * step + off);
                     v[k][j].y = (T)0;
                 } else {
@@ -511,7 +536,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                 for (int f = tid; f < total; f += C::THREADS) {
                     const int c = f / C::N, n = f - c * C::N;
                     V x = {(T)0, (T)0};
-                    if constexpr (C::IN_REAL)
+                    if constexpr (!same_t<typename C::IT, T>::value)
+                        x = load_foreign<C>(p.in, base + f);
+                    else if constexpr (C::IN_REAL)
                         x.x = gload_real<(C::NT & 1) != 0>((const T*)p.in + base + f);
                     else
                         x = gload<(C::NT & 1) != 0>(gin + base + f);

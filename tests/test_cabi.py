@@ -101,10 +101,13 @@ def test_jit_precompile_needs_no_device():
     from hackathon_fft_amd import _lib
     L = _lib.lib()
     sz = ctypes.c_size_t(0)
-    assert L.mifft_jit_precompile(0, 49, 0, 0, ctypes.byref(sz)) == 0
+    assert L.mifft_jit_precompile(0, 0, 49, 0, 0, ctypes.byref(sz)) == 0
     assert sz.value > 4096
-    assert L.mifft_jit_precompile(0, 77, 1, 0, ctypes.byref(sz)) == 0      # strided form
-    assert L.mifft_jit_precompile(1, 121, 0, 0, ctypes.byref(sz)) == 0     # fp64
-    assert L.mifft_jit_precompile(0, 97, 0, 0, ctypes.byref(sz)) == -9
+    assert L.mifft_jit_precompile(0, 0, 77, 1, 0, ctypes.byref(sz)) == 0   # strided form
+    assert L.mifft_jit_precompile(1, 1, 121, 0, 0, ctypes.byref(sz)) == 0  # fp64
+    assert L.mifft_jit_precompile(2, 0, 480, 0, 1, ctypes.byref(sz)) == 0  # uint8 real input widened in the load
+    assert L.mifft_jit_precompile(3, 0, 96, 0, 0, ctypes.byref(sz)) == 0   # int32 complex input
+    assert L.mifft_jit_precompile(0, 1, 93, 0, 0, ctypes.byref(sz)) == 0   # float input under a double plan
+    assert L.mifft_jit_precompile(0, 0, 97, 0, 0, ctypes.byref(sz)) == -9
     assert b"fused" in L.mifft_last_error()
-    assert L.mifft_jit_precompile(5, 49, 0, 0, ctypes.byref(sz)) == -4
+    assert L.mifft_jit_precompile(0, 5, 49, 0, 0, ctypes.byref(sz)) == -4

@@ -95,14 +95,36 @@ def test_results_do_not_depend_on_the_tile_slot_jit():
         assert np.array_equal(out[i], out[0]), i
 
 
-def test_lengths_outside_the_jit_stay_on_the_literal_stages(monkeypatch):
+def test_lengths_outside_the_jit_stay_on_the_literal_stages():
     rng = np.random.default_rng(1)
     x = rng.standard_normal((5, 97, 2)).astype(np.float32)    # prime > 31
     out, plan = _run(x)
     assert plan.kernel_name(0) == "generic"
     assert rel_l2(out, O.fftn(x)) < REL_L2_TOL_F32
-    x8 = rng.integers(0, 255, size=(5, 49, 2)).astype(np.uint8)   # integer input: generic family
-    xt = torch.from_numpy(x8).to("cuda:0")
-    o = torch.empty((5, 49, 2), device="cuda:0")
-    p = mf.plan_fft(torch.uint8, torch.float32, xt.shape, o.shape)
-    assert p.kernel_name(0) == "generic"
+
+
+@pytest.mark.parametrize("in_dtype,comps", [(np.uint8, 1), (np.uint8, 2), (np.int32, 1), (np.int32, 2)])
+@pytest.mark.parametrize("shape", [(9, 1024), (5, 49), (3, 40, 48), (2, 1080, 1920)])
+def test_integer_input_is_widened_in_the_first_pass(in_dtype, comps, shape):
+    """uint8 / int32 tensors (images) run on the fused kernels: the pass that reads x is specialised for the input
+    element type (the reference casts in its load, fft/fft/_fft.mojo:243-251); later passes are the table kernels."""
+    rng = np.random.default_rng(sum(shape) + comps)
+    hi = 255 if in_dtype == np.uint8 else 100000
+    x = rng.integers(0, hi, size=shape + (comps,)).astype(in_dtype)
+    out, plan = _run(x, out_dtype=torch.float32)
+    last = plan.kernel_name(len(shape) - 2)
+    assert last.endswith("_jit") and ("_u8" in last or "_i32" in last), last
+    xc = x[..., 0].astype(np.float64) + (1j * x[..., 1] if comps == 2 else 0)
+    truth = np.fft.fftn(xc, axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
+    if np.prod(shape) <= 20000:
+        assert rel_l2(out, O.fftn(x, out_dtype=np.float32)) < REL_L2_TOL_F32
+
+
+def test_float_input_under_a_double_plan():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((6, 480, 2)).astype(np.float32)
+    out, plan = _run(x, out_dtype=torch.float64)
+    assert plan.kernel_name(0).endswith("_f32in_jit"), plan.kernel_name(0)
+    truth = np.fft.fft(to_complex(x.astype(np.float64)), axis=1)
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F64
