@@ -128,7 +128,8 @@ static hipError_t upload_col_table(int64_t N, int64_t n1, int tile, void** d_tab
 }
 
 // one column-tile pass of length n with element stride `inner`: fused table first, literal-stage fallback
-static bool make_cols_pass(const Plan& plan, int dim_index, int64_t n, int64_t inner, DimPass& ps, std::string& why) {
+static bool make_cols_pass(const Plan& plan, int dim_index, int64_t n, int64_t inner, DimPass& ps, std::string& why,
+                           bool allow_jit = false) {
     ps = DimPass();
     ps.dim_index = dim_index;
     ps.N = n;
@@ -136,6 +137,10 @@ static bool make_cols_pass(const Plan& plan, int dim_index, int64_t n, int64_t i
     ps.outer = 1;
     ps.first = false;
     if (select_fast(plan, ps)) return true;
+    if (allow_jit) {
+        std::string whyj;
+        if (select_jit(plan, ps, whyj)) return true;
+    }
     std::vector<uint64_t> user = plan_estimate_bases((uint64_t)n, true);
     std::string err;
     if (plan_ordered_bases((uint64_t)n, user, ps.radices, ps.processed, err) != MIFFT_OK) {
@@ -147,10 +152,9 @@ static bool make_cols_pass(const Plan& plan, int dim_index, int64_t n, int64_t i
 
 bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
     const int64_t N = plan.dims[dim_index];
-    if (plan.in_components != 2 || plan.in_dtype != plan.out_dtype) {
-        why_not = "needs complex input of the output dtype";
-        return false;
-    }
+    // real / integer / mixed-precision input is widened by the first pass, which then has to be the runtime-specialised
+    // transposed-store kernel (two-launch form); the three-launch fallback reads complex input of the output dtype
+    const bool native_in = plan.in_components == 2 && plan.in_dtype == plan.out_dtype;
     // N = N1 * N2, both factors at most 4096, as balanced as possible, preferring lengths with fused kernels
     int64_t best1 = 0, best2 = 0;
     double best_score = 1e300;
@@ -162,12 +166,16 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
         std::string w;
         Plan probe = plan;  // selection only reads the plan
         probe.passes.clear();
-        const bool fa = make_cols_pass(probe, dim_index, n1, n2, a, w) && std::string(a.kernel_name) != "generic";
-        const bool fb = make_cols_pass(probe, dim_index, n2, n1, b, w) && std::string(b.kernel_name) != "generic";
+        const bool fa = (make_cols_pass(probe, dim_index, n1, n2, a, w) && std::string(a.kernel_name) != "generic") ||
+                        jit_cols_feasible(plan, n1, n2);
+        const bool fb = (make_cols_pass(probe, dim_index, n2, n1, b, w) && std::string(b.kernel_name) != "generic") ||
+                        jit_cols_feasible(plan, n2, n1);
         DimPass ts;
         ts.N = n1;
         ts.inner = n2;
-        const bool two_pass = fb && select_fast_tstore(probe, ts);  // no middle pass, no scratch
+        // no middle pass, no scratch
+        const bool two_pass = fb && ((native_in && select_fast_tstore(probe, ts)) || jit_tstore_feasible(plan, n1, n2));
+        if (!native_in && !two_pass) continue;
         double score = std::fabs(std::log((double)n1 / (double)n2)) + (fa || two_pass ? 0 : 4) + (fb ? 0 : 4) -
                        (two_pass ? 3 : 0);
         if (score < best_score) {
@@ -177,11 +185,12 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
         }
     }
     if (!best1) {
-        why_not = "no factorisation N1 * N2 with both factors <= 4096";
+        why_not = native_in ? "no factorisation N1 * N2 with both factors <= 4096"
+                            : "no two-pass factorisation N1 * N2 (needed for real / integer / mixed-precision input)";
         return false;
     }
     DimPass p1, p3, p2;
-    if (!make_cols_pass(plan, dim_index, best2, best1, p3, why_not)) return false;
+    if (!make_cols_pass(plan, dim_index, best2, best1, p3, why_not, true)) return false;
     // two-pass form: the first column pass stores transposed + twiddled straight into `out` (no scratch)
     {
         DimPass ts;
@@ -189,8 +198,9 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
         ts.N = best1;
         ts.inner = best2;
         ts.outer = 1;
-        ts.first = false;
-        if (select_fast_tstore(plan, ts)) {
+        ts.first = !native_in;  // reads x with its own element type / component count
+        std::string whyts;
+        if ((native_in && select_fast_tstore(plan, ts)) || select_jit_tstore(plan, ts, whyts)) {
             ts.src_buf = 0;  // x
             ts.dst_buf = 1;  // out
             p3.src_buf = 1;
@@ -215,7 +225,11 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
             return true;
         }
     }
-    if (!make_cols_pass(plan, dim_index, best1, best2, p1, why_not)) return false;
+    if (!native_in) {
+        why_not = "the transposed-store kernel could not be built for real / integer / mixed-precision input";
+        return false;
+    }
+    if (!make_cols_pass(plan, dim_index, best1, best2, p1, why_not, true)) return false;
     p1.src_buf = 0;  // x
     p1.dst_buf = 2;  // scratch
     p3.src_buf = 1;  // out, in place

@@ -95,6 +95,11 @@ bool select_generic(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_fast(const Plan& plan, DimPass& pass);
 // the tile kernel specialised at plan time with hipRTC for a length without a table entry (kernels_jit.cpp)
 bool select_jit(const Plan& plan, DimPass& pass, std::string& why_not);
+// four-step helpers: the transposed + twiddled column pass (reads x: real / integer input allowed) and cheap
+// feasibility predicates for scoring factorisations without compiling
+bool select_jit_tstore(const Plan& plan, DimPass& pass, std::string& why_not);
+bool jit_tstore_feasible(const Plan& plan, int64_t n1, int64_t n2);
+bool jit_cols_feasible(const Plan& plan, int64_t n, int64_t inner);
 int jit_precompile(int in_dtype, int out_dtype, int64_t n, int cols, int in_real, size_t* code_bytes, std::string& why);
 // fused pass over the two innermost dimensions (pass.N = contiguous dim, pass.N1 = the next one)
 bool select_fast_plane(const Plan& plan, DimPass& pass);
