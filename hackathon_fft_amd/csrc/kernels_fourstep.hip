@@ -75,7 +75,7 @@ static int launch_transpose_twiddle(const Plan& plan, const DimPass& pass, const
     tp.thi = pass.d_aux2;
     tp.n1 = pass.fs_n1;
     tp.n2 = pass.fs_n2;
-    tp.batch = count * pass.outer;  // matrices per exec (outer = 1 for the four-step)
+    tp.batch = count * pass.outer;  // matrices per exec
     tp.inverse = plan.inverse;
     tp.apply_tw = pass.d_aux != nullptr;
     dim3 grid((unsigned)((pass.fs_n2 + 31) / 32), (unsigned)((pass.fs_n1 + 31) / 32),
@@ -135,6 +135,7 @@ static bool make_cols_pass(const Plan& plan, int dim_index, int64_t n, int64_t i
     ps.N = n;
     ps.inner = inner;
     ps.outer = 1;
+    for (int k = 0; k < dim_index; ++k) ps.outer *= plan.dims[k];  // 1 for a batched 1-D transform
     ps.first = false;
     if (select_fast(plan, ps)) return true;
     if (allow_jit) {
@@ -197,7 +198,7 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
         ts.dim_index = dim_index;
         ts.N = best1;
         ts.inner = best2;
-        ts.outer = 1;
+        ts.outer = p3.outer;
         ts.first = !native_in;  // reads x with its own element type / component count
         std::string whyts;
         if ((native_in && select_fast_tstore(plan, ts)) || select_jit_tstore(plan, ts, whyts)) {
@@ -235,6 +236,7 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
     p3.src_buf = 1;  // out, in place
     p3.dst_buf = 1;
     p2.dim_index = dim_index;
+    p2.outer = p3.outer;
     p2.N = N;
     p2.fs_n1 = best1;
     p2.fs_n2 = best2;

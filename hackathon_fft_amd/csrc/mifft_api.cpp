@@ -318,7 +318,7 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                 // too long for one workgroup's LDS: four-step over two column-tile passes (contiguous dim of a
                 // batched 1-D complex transform; the reference has no path at all here off NVIDIA clusters)
                 std::string why4;
-                if (ndim == 1 && build_fourstep(p, i, why4)) continue;
+                if (i == ndim - 1 && build_fourstep(p, i, why4)) continue;
                 free_plan_device(p);
                 delete h;
                 return set_error(MIFFT_ERR_TOO_LARGE, why + (why4.empty() ? "" : "; four-step: " + why4));

@@ -331,6 +331,22 @@ def test_four_step_real_integer_and_mixed_input(n, in_dtype, comps, out_dtype):
     assert rel_l2(out, from_complex(truth, np.float64)) < tol
 
 
+@pytest.mark.parametrize("shape,comps", [((2, 6, 32768), 2), ((1, 3, 5, 20480), 2), ((2, 4, 65536), 1), ((1, 64, 1 << 17), 2)])
+def test_four_step_on_the_contiguous_dimension_of_an_nd_transform(shape, comps):
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape + (comps,)).astype(np.float32)
+    out, plan = gpu_fft(x, out_dtype=np.float32)
+    last = len(shape) - 2
+    assert "_ts" in plan.kernel_name(last), plan.kernel_name(last)
+    assert plan.num_launches == len(shape)      # two for the long dimension, one per other dimension
+    xc = x[..., 0].astype(np.float64) + (1j * x[..., 1].astype(np.float64) if comps == 2 else 0)
+    truth = np.fft.fftn(xc, axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
+    if comps == 2:
+        back, _ = gpu_fft(out, inverse=True, out_dtype=np.float32)
+        assert rel_l2(back, x) < REL_L2_TOL_F32
+
+
 @pytest.mark.parametrize("shape", [(1, 7680, 64), (2, 5120, 40), (1, 8192, 3, 5), (1, 6144, 100)])
 def test_long_strided_dimension_through_transposes(shape):
     """A strided dimension beyond the column-tile table (8K-video columns): transpose -> row kernel -> transpose

@@ -98,7 +98,8 @@ def test_plan_lifecycle():
 
 
 @pytest.mark.parametrize("shape,kw", [((2000, 1024), dict(bases=[[2]])), ((8, 640, 480), {}), ((3, 16384), {}),
-                                      ((4, 7680), dict(faithful_stages=True))])
+                                      ((4, 7680), dict(faithful_stages=True)), ((500, 343), {}),   # runtime-specialised (module launch)
+                                      ((2, 1 << 20), {}), ((3, 128, 128), {})])           # four-step, fused plane
 def test_exec_is_capturable_into_a_hip_graph(shape, kw):
     """exec enqueues kernels only (no allocation, no attribute call, no sync): it can be captured and replayed."""
     g = torch.Generator(device=DEV).manual_seed(3)
