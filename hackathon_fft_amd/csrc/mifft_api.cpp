@@ -262,7 +262,8 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                 pl.N1 = dims[i - 1];
                 pl.outer = 1;
                 for (int k = 0; k < i - 1; ++k) pl.outer *= dims[k];
-                if (select_fast_plane(p, pl)) {
+                std::string whyp;
+                if (select_fast_plane(p, pl) || select_jit_plane(p, pl, whyp)) {
                     ps = pl;
                     ok = true;
                     --i;  // dimension i-1 is covered by this pass

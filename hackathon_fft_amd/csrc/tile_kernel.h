@@ -673,7 +673,11 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
     static_assert(CR::FIRST_DIRECT && !CR::LAST_DIRECT && !CC::FIRST_DIRECT && CC::LAST_DIRECT, "plane data flow");
     static_assert(CR::TWMODE == TW_LDS && CC::TWMODE == TW_LDS && CR::N == CC::N && CR::TWL_TOTAL == CC::TWL_TOTAL,
                   "square planes with one shared LDS twiddle table");
+#ifdef MIFFT_STATIC_LDS
+    __shared__ __attribute__((aligned(16))) unsigned char smem[CR::LDS_BYTES];
+#else
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
     V* lds = (V*)smem;
     const int tid0 = threadIdx.x;
     V twr[1];

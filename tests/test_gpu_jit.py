@@ -76,6 +76,33 @@ def test_real_input_twin(n):
     assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
 
 
+@pytest.mark.parametrize("shape,dtype,comps", [((5, 32, 32), np.float32, 2), ((3, 96, 96), np.float32, 2),
+                                               ((2, 100, 100), np.float32, 2), ((7, 48, 48), np.float32, 1),
+                                               ((2, 3, 120, 120), np.float32, 2), ((3, 64, 64), np.float64, 2),
+                                               ((2, 64, 64), np.uint8, 1), ((300, 16, 16), np.float32, 2),
+                                               ((260, 126, 126), np.float32, 2)])
+def test_square_planes_are_fused(shape, dtype, comps):
+    """Two equal innermost dimensions whose plane fits LDS run as ONE pass (plane_kernel specialised at plan time):
+    rows from HBM, columns inside LDS, one store."""
+    rng = np.random.default_rng(sum(shape) + comps)
+    if dtype == np.uint8:
+        x = rng.integers(0, 255, size=shape + (comps,)).astype(dtype)
+    else:
+        x = rng.standard_normal(shape + (comps,)).astype(dtype)
+    odt = torch.float64 if dtype == np.float64 else torch.float32
+    out, plan = _run(x, out_dtype=odt)
+    nd = len(shape) - 1
+    assert plan.kernel_name(nd - 1).startswith("plane") and plan.kernel_name(nd - 2) == plan.kernel_name(nd - 1)
+    assert plan.num_launches == nd - 1
+    xc = x[..., 0].astype(np.float64) + (1j * x[..., 1].astype(np.float64) if comps == 2 else 0)
+    truth = np.fft.fftn(xc, axes=tuple(range(1, len(shape))))
+    tol = REL_L2_TOL_F64 if dtype == np.float64 else REL_L2_TOL_F32
+    assert rel_l2(out, from_complex(truth, np.float64)) < tol
+    if comps == 2 and dtype != np.uint8:
+        back, _ = _run(out, inverse=True)
+        assert rel_l2(back, x) < tol
+
+
 def test_mixed_nd_with_a_jit_dimension():
     rng = np.random.default_rng(5)
     x = rng.standard_normal((2, 49, 12, 121, 2)).astype(np.float32)
