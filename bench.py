@@ -185,6 +185,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock / cache ramp: a short --warmup (a few ms of work) leaves the first timed steps 10-20 % slow, so the device
+    # is kept busy for >= 50 ms before the W warmup steps (untimed, outside the K timed steps)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.05:
+        for _ in range(10):
+            mf.fft(out, x, ctx, plan=plan)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         mf.fft(out, x, ctx, plan=plan)
     barrier()
