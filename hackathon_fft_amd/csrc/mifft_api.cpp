@@ -241,7 +241,9 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
     // ---- passes in execution order: last dimension first ----
     p.stage_radices = ordered;
     auto upload_twiddles = [&](DimPass& ps) -> hipError_t {
-        return upload_twiddle_table(out_dtype, ps.N, inverse != 0, &ps.d_twiddle);
+        hipError_t e = upload_twiddle_table(out_dtype, ps.N, inverse != 0, &ps.d_twiddle);
+        if (e == hipSuccess && ps.plane_needs_tw1) e = upload_twiddle_table(out_dtype, ps.N1, inverse != 0, &ps.d_aux);
+        return e;
     };
     for (int i = ndim - 1; i >= 0; --i) {
         DimPass ps;

@@ -65,6 +65,7 @@ struct DimPass {
     int src_buf = -1, dst_buf = -1;
     int64_t fs_n1 = 0, fs_n2 = 0;  // four-step factors of the dimension (transpose + twiddle pass)
     void* d_aux2 = nullptr;
+    bool plane_needs_tw1 = false;     // rectangular fused plane: d_aux holds the W_N1 table of the column side
     void* jit_fn = nullptr;           // runtime-compiled kernel (hipFunction_t) of kernels_jit.cpp passes
     void* d_aux3 = nullptr;           // TSTORE passes: [tile][N] table of W^(c*k1) for the columns of one tile
 };

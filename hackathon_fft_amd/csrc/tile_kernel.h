@@ -435,7 +435,8 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
     }
 }
 
-template <class C, int I>
+// TWSHIFT: extra offset of this configuration's LDS twiddle table (rectangular planes keep two tables)
+template <class C, int I, int TWSHIFT = 0>
 MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<typename C::T>* twr,
                         cpx<typename C::T> (*pre)[C::R(0)], long long base, int nv, int tid) {
     if constexpr (I < C::NP) {
@@ -461,14 +462,14 @@ MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<
                     for (int j = 0; j < R; ++j) v[k][j].y = -v[k][j].y;
             }
         } else {
-            pass_gather_lds<C, I>(p, lds, lds + C::DATA_ELEMS, twr, v, tid);
+            pass_gather_lds<C, I>(p, lds, lds + C::DATA_ELEMS + TWSHIFT, twr, v, tid);
             // in-place LDS buffer: every read of this pass completes before any later write (this
             // pass's scatter, or pass 0 of the NEXT tile when this pass stores to HBM)
             wg_barrier<C>();
         }
         pass_compute_scatter<C, I>(p, lds, v, base, nv, tid);
         if constexpr (!DST_GLOBAL) wg_barrier<C>();
-        run_pass<C, I + 1>(p, lds, twr, pre, base, nv, tid);
+        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid);
     }
 }
 
@@ -671,10 +672,16 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
     static_assert(CR::N == CC::TILE && CR::TILE == CC::N && CR::LD == CR::N, "plane geometry");
     static_assert(CR::THREADS == CC::THREADS, "one thread count");
     static_assert(CR::FIRST_DIRECT && !CR::LAST_DIRECT && !CC::FIRST_DIRECT && CC::LAST_DIRECT, "plane data flow");
-    static_assert(CR::TWMODE == TW_LDS && CC::TWMODE == TW_LDS && CR::N == CC::N && CR::TWL_TOTAL == CC::TWL_TOTAL,
-                  "square planes with one shared LDS twiddle table");
+    static_assert(CR::TWMODE == TW_LDS && CC::TWMODE == TW_LDS, "planes keep their twiddles in LDS");
+    // square planes with the same radices share one LDS twiddle table; rectangular planes keep the column table (W_N1,
+    // from p.tlo) right behind the row table (W_N2, from p.tw)
+    constexpr bool SHARED_TW = CR::N == CC::N && CR::NP == CC::NP && CR::R(0) == CC::R(0) && CR::R(1) == CC::R(1) &&
+                               CR::R(2) == CC::R(2) && CR::R(3) == CC::R(3);
+    constexpr int CSHIFT = SHARED_TW ? 0 : CR::TWL_TOTAL;
+    constexpr size_t PLANE_LDS = (size_t)(CR::DATA_ELEMS + CSHIFT + CC::TWL_TOTAL) * sizeof(V);
+    static_assert(CR::DATA_ELEMS == CC::DATA_ELEMS && PLANE_LDS <= 160 * 1024, "plane + twiddle tables must fit LDS");
 #ifdef MIFFT_STATIC_LDS
-    __shared__ __attribute__((aligned(16))) unsigned char smem[CR::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PLANE_LDS];
 #else
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
@@ -682,6 +689,7 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
     const int tid0 = threadIdx.x;
     V twr[1];
     fill_lds_tw<CR, 1>(lds + CR::DATA_ELEMS, (const V*)p.tw, tid0, p.inverse);
+    if constexpr (!SHARED_TW) fill_lds_tw<CC, 1>(lds + CR::DATA_ELEMS + CSHIFT, (const V*)p.tlo, tid0, p.inverse);
     __syncthreads();
 
     constexpr long long PLANE = (long long)CR::N * CR::TILE;
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
         }
         run_pass<CR, 0>(p, lds, twr, cur, base, CR::TILE, tid);  // rows: HBM -> ... -> LDS (natural order)
         V none[1][CC::R(0)];
-        run_pass<CC, 0>(p, lds, twr, none, base, CC::TILE, tid);  // columns: LDS -> ... -> HBM
+        run_pass<CC, 0, CSHIFT>(p, lds, twr, none, base, CC::TILE, tid);  // columns: LDS -> ... -> HBM
     }
 }
 

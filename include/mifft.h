@@ -186,7 +186,8 @@ int mifft_time_exec(const mifft_plan* plan, const void* x, void* out, void* stre
  * device: usable to warm the cache ahead of plan creation or to check a length on a build machine.
  * in_dtype: element type of the tensor the pass reads (any mifft_dtype; widened to out_dtype in the load);
  * out_dtype: MIFFT_F32 / MIFFT_F64; strided: 0 contiguous rows, 1 the in-place column-tile form, 2 a fused
- * length x length plane (two innermost dimensions in one LDS tile); real_input != 0: the C_in = 1 twin.
+ * length x length plane (two innermost dimensions in one LDS tile), k >= 8 a fused k x length plane (length = the
+ * contiguous side); real_input != 0: the C_in = 1 twin.
  * Returns MIFFT_OK, or MIFFT_ERR_TOO_LARGE when the length has no fused configuration (a prime factor above 31,
  * or a tile beyond the 160 KiB of LDS) -- such lengths run on the literal-stage kernels.
  */

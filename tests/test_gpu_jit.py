@@ -80,10 +80,15 @@ def test_real_input_twin(n):
                                                ((2, 100, 100), np.float32, 2), ((7, 48, 48), np.float32, 1),
                                                ((2, 3, 120, 120), np.float32, 2), ((3, 64, 64), np.float64, 2),
                                                ((2, 64, 64), np.uint8, 1), ((300, 16, 16), np.float32, 2),
-                                               ((260, 126, 126), np.float32, 2)])
-def test_square_planes_are_fused(shape, dtype, comps):
-    """Two equal innermost dimensions whose plane fits LDS run as ONE pass (plane_kernel specialised at plan time):
-    rows from HBM, columns inside LDS, one store."""
+                                               ((260, 126, 126), np.float32, 2),
+                                               # rectangular planes: two LDS twiddle tables
+                                               ((5, 64, 128), np.float32, 2), ((5, 128, 64), np.float32, 2),
+                                               ((3, 96, 160), np.float32, 2), ((7, 40, 48), np.float32, 1),
+                                               ((2, 3, 120, 100), np.float32, 2), ((3, 32, 64), np.float64, 2),
+                                               ((9, 32, 512), np.float32, 2), ((300, 24, 16), np.float32, 2)])
+def test_planes_are_fused(shape, dtype, comps):
+    """Two innermost dimensions whose plane fits LDS run as ONE pass (plane_kernel specialised at plan time): rows
+    from HBM, columns inside LDS, one store."""
     rng = np.random.default_rng(sum(shape) + comps)
     if dtype == np.uint8:
         x = rng.integers(0, 255, size=shape + (comps,)).astype(dtype)
