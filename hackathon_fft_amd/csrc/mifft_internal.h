@@ -98,6 +98,7 @@ bool select_fast(const Plan& plan, DimPass& pass);
 bool select_jit(const Plan& plan, DimPass& pass, std::string& why_not);
 // four-step helpers: the transposed + twiddled column pass (reads x: real / integer input allowed) and cheap
 // feasibility predicates for scoring factorisations without compiling
+bool select_jit_streaming_rows(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_jit_plane(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_jit_tstore(const Plan& plan, DimPass& pass, std::string& why_not);
 bool jit_tstore_feasible(const Plan& plan, int64_t n1, int64_t n2);
