@@ -409,6 +409,22 @@ int main(int argc, char** argv) {
         V("r16384 16x16x16x4 1024 glb w4 pf", float, 16384, 4, 16, 16, 16, 4, 1, 1024, false, true, true, TW_GLOBAL, 4, true),
         VN("r16384 16x16x8x8 1024 glb w4 pf nt3", 3, float, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, true),
     };
+#elif GROUP == 16  // ---- streaming-size non-power-of-two rows: 100k x 1000 (800 MB) ----
+    const long long batch = 100000, outer = 1, inner = 1;
+    const int N = 1000;
+    std::vector<Variant> vs = {
+        VN("10x10x10 t4 256 lds w1 nt0", 0, float, 1000, 3, 10, 10, 10, 1, 4, 256, false, true, true, TW_LDS, 1, false),
+        VN("10x10x10 t4 256 lds w1 nt3", 3, float, 1000, 3, 10, 10, 10, 1, 4, 256, false, true, true, TW_LDS, 1, false),
+        VN("10x10x10 t4 512 lds w2 nt3", 3, float, 1000, 3, 10, 10, 10, 1, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("10x10x10 t4 512 lds w2 nt0", 0, float, 1000, 3, 10, 10, 10, 1, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("5x5x5x8 t4 512 lds w2 nt3", 3, float, 1000, 4, 5, 5, 5, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("8x5x5x5 t4 512 lds w2 nt3", 3, float, 1000, 4, 8, 5, 5, 5, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("5x5x5x8 t4 512 lds w2 nt0", 0, float, 1000, 4, 5, 5, 5, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("10x10x10 t8 512 lds w2 nt3", 3, float, 1000, 3, 10, 10, 10, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+        VN("10x10x10 t4 256 lds w1 nt2", 2, float, 1000, 3, 10, 10, 10, 1, 4, 256, false, true, true, TW_LDS, 1, false),
+        VN("10x10x10 t4 256 lds w1 nt1", 1, float, 1000, 3, 10, 10, 10, 1, 4, 256, false, true, true, TW_LDS, 1, false),
+        VN("10x10x10 t2 256 lds w2 nt3", 3, float, 1000, 3, 10, 10, 10, 1, 2, 256, false, true, true, TW_LDS, 2, false),
+    };
 #else
 #error "define GROUP"
 #endif
