@@ -170,13 +170,21 @@ struct TileCfg {
     static constexpr int CPITCH = TSTORE_ ? TILE_ + 1 : TILE_;
     static_assert(!TSTORE_ || (COLS_ && !LAST_DIRECT_ && FIRST_DIRECT_), "TSTORE: column tile, last pass left in LDS");
     static constexpr int DATA_ELEMS = COLS_ ? N_ * CPITCH : LD * TILE_;
+    // BIGP0: the first radix is a prime too large for a register butterfly (> 32).  Pass 0 then runs cooperatively in
+    // LDS (bigprime_pass0): the row is staged by the flat copy, paired into sums / differences in place, and every
+    // thread accumulates a few output pairs over the (R-1)/2 pairs with a cos/sin table of R entries kept behind the
+    // twiddle table.  Rows only; instantiated by the runtime-specialised kernels.
+    static constexpr bool BIGP0 = R0_ > 32;
+    static constexpr int CS_ELEMS = BIGP0 ? R0_ : 0;
+    static_assert(!BIGP0 || (!COLS_ && !FIRST_DIRECT_ && TWMODE_ == TW_LDS), "big-prime pass 0: flat-copied rows");
     // DMA: the flat HBM -> LDS copy of the NEXT tile runs asynchronously (global_load_lds) into a staging
     // buffer behind the twiddle table while this tile's passes execute
     static constexpr bool DMA = DMA_;
     static constexpr int STAGE_OFF = ((DATA_ELEMS + TWL_TOTAL) * 2 * (int)sizeof(T_) + 15) / 16 * 16 / (2 * (int)sizeof(T_));
     static constexpr int STAGE_ELEMS = DMA_ ? N_ * TILE_ : 0;
     static constexpr size_t LDS_BYTES =
-        DMA_ ? (size_t)(STAGE_OFF + STAGE_ELEMS) * 2 * sizeof(T_) : (size_t)(DATA_ELEMS + TWL_TOTAL) * 2 * sizeof(T_);
+        DMA_ ? (size_t)(STAGE_OFF + STAGE_ELEMS) * 2 * sizeof(T_)
+             : (size_t)(DATA_ELEMS + TWL_TOTAL + CS_ELEMS) * 2 * sizeof(T_);
     static_assert(P(NP_) == N_, "radices must multiply to N");
     static_assert(LDS_BYTES <= 160 * 1024, "tile + twiddle table exceed the CU's 160 KiB of LDS");
 };
@@ -435,11 +443,76 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
     }
 }
 
+// Pass 0 for a prime radix R > 32 (C::BIGP0), cooperatively in LDS.  The tile has been staged by the flat copy.
+//   1. in place: a_j = x_j + x_{R-j} at position j, b_j = x_j - x_{R-j} at position R-j   (j = 1..H, H = (R-1)/2)
+//   2. item (transform, butterfly, s), s = 0..H:  A = x_0 + sum_j cos(2 pi j s / R) a_j,  B = sum_j sin(2 pi j s / R) b_j
+//      X_s = A - iB, X_{R-s} = A + iB  -- the conjugate-pair form of DftOddPrime, 4 real FMAs per (j, pair) instead of
+//      the 8 of the literal stage (fft/fft/_fft.mojo:261-290); lanes that share a butterfly read a_j, b_j as broadcasts
+//   3. after a barrier the outputs go to their Stockham positions b*R + s (pass 0: P = 1)
+template <class C>
+MIFFT_DEV void bigprime_pass0(cpx<typename C::T>* lds, const cpx<typename C::T>* cs, int tid) {
+    using T = typename C::T;
+    using V = cpx<T>;
+    constexpr int R = C::R(0), H = (R - 1) / 2, NB = C::NB(0);
+    constexpr int PAIRS = C::TILE * NB * H;
+    for (int e = tid; e < PAIRS; e += C::THREADS) {
+        const int c = e / (NB * H), rem = e - c * (NB * H);
+        const int b = rem / H, j = rem - b * H + 1;
+        const int i1 = lds_index<C, -1>(c, b + j * NB), i2 = lds_index<C, -1>(c, b + (R - j) * NB);
+        const V u = lds[i1], v = lds[i2];
+        lds[i1] = u + v;
+        lds[i2] = u - v;
+    }
+    __syncthreads();
+    constexpr int ITEMS = C::TILE * NB * (H + 1);
+    constexpr int IPT = (ITEMS + C::THREADS - 1) / C::THREADS;
+    V lo[IPT], hi[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int id = tid + k * C::THREADS;
+        if (id < ITEMS) {
+            const int cb = id / (H + 1), s = id - cb * (H + 1);
+            const int c = cb / NB, b = cb - c * NB;
+            const V x0 = lds[lds_index<C, -1>(c, b)];
+            V A = x0, B = {(T)0, (T)0};
+            int m = 0;
+#pragma unroll 2
+            for (int j = 1; j <= H; ++j) {
+                m += s;
+                if (m >= R) m -= R;
+                const V a = lds[lds_index<C, -1>(c, b + j * NB)], d = lds[lds_index<C, -1>(c, b + (R - j) * NB)];
+                const V w = cs[m];  // (cos, sin)(2 pi m / R)
+                A.x = fma_t(w.x, a.x, A.x);
+                A.y = fma_t(w.x, a.y, A.y);
+                B.x = fma_t(w.y, d.x, B.x);
+                B.y = fma_t(w.y, d.y, B.y);
+            }
+            lo[k] = {A.x + B.y, A.y - B.x};  // X_s
+            hi[k] = {A.x - B.y, A.y + B.x};  // X_{R-s}
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int id = tid + k * C::THREADS;
+        if (id < ITEMS) {
+            const int cb = id / (H + 1), s = id - cb * (H + 1);
+            const int c = cb / NB, b = cb - c * NB;
+            lds[lds_index<C, 0>(c, b * R + s)] = lo[k];
+            if (s > 0) lds[lds_index<C, 0>(c, b * R + R - s)] = hi[k];
+        }
+    }
+    __syncthreads();
+}
+
 // TWSHIFT: extra offset of this configuration's LDS twiddle table (rectangular planes keep two tables)
 template <class C, int I, int TWSHIFT = 0>
 MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<typename C::T>* twr,
                         cpx<typename C::T> (*pre)[C::R(0)], long long base, int nv, int tid) {
-    if constexpr (I < C::NP) {
+    if constexpr (I == 0 && C::BIGP0) {
+        bigprime_pass0<C>(lds, lds + C::DATA_ELEMS + C::TWL_TOTAL, tid);
+        run_pass<C, 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid);
+    } else if constexpr (I < C::NP) {
         using T = typename C::T;
         using V = cpx<T>;
         constexpr int R = C::R(I), IPT = C::IPT(I);
@@ -488,6 +561,13 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
     if constexpr (C::TWMODE == TW_REG) preload_tw<C, 1>(twr, (const V*)p.tw, tid0, p.inverse);
     if constexpr (C::TWMODE == TW_LDS) {
         fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, tid0, p.inverse);
+        if constexpr (C::BIGP0) {  // (cos, sin)(2 pi m / R0) from W_N^(m N/R0) = cos - i sin
+            for (int m = tid0; m < C::R(0); m += C::THREADS) {
+                V w = ((const V*)p.tw)[m * C::NB(0)];
+                if (p.inverse) w.y = -w.y;
+                lds[C::DATA_ELEMS + C::TWL_TOTAL + m] = {w.x, -w.y};
+            }
+        }
         __syncthreads();
     }
 

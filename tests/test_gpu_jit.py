@@ -127,12 +127,62 @@ def test_results_do_not_depend_on_the_tile_slot_jit():
         assert np.array_equal(out[i], out[0]), i
 
 
+# lengths with ONE prime factor in (31, 127]: that factor is pass 0, run cooperatively in LDS (TileCfg::BIGP0)
+BIG_PRIME_ROWS = [97, 37, 74, 123, 127, 194, 101, 113, 122, 555, 328, 89 * 12, 4 * 9 * 43]
+
+
+@pytest.mark.parametrize("n", BIG_PRIME_ROWS)
+def test_rows_with_a_large_prime_factor(n):
+    rng = np.random.default_rng(n)
+    batch = 131 if n <= 512 else 9
+    x = rng.standard_normal((batch, n, 2)).astype(np.float32)
+    bases = None
+    try:
+        out, plan = _run(x)
+    except mf.MifftError:   # the reference's default radix estimate stops at 97 / trial division by 2..32: pass bases
+        f, m, d = [], n, 2
+        while m > 1:
+            while m % d == 0:
+                f.append(d)
+                m //= d
+            d += 1
+        bases = [sorted(set(f))]
+        out, plan = _run(x, bases=bases)
+    assert plan.kernel_name(0).endswith("_jit"), plan.kernel_name(0)
+    assert not np.isnan(out).any()
+    truth = np.fft.fft(to_complex(x), axis=1)
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32, plan.kernel_name(0)
+    if n <= 600:
+        assert rel_l2(out, O.fftn(x, bases=bases)) < REL_L2_TOL_F32
+    back, _ = _run(out, inverse=True, bases=bases)
+    assert rel_l2(back, x) < REL_L2_TOL_F32
+
+
+def test_large_prime_factor_fp64_and_real_and_uint8():
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((40, 97, 2))
+    out, plan = _run(x)
+    assert plan.kernel_name(0).endswith("_jit")
+    assert rel_l2(out, O.fftn(x)) < REL_L2_TOL_F64
+    xr = rng.standard_normal((33, 74, 1)).astype(np.float32)
+    out, plan = _run(xr)
+    assert plan.kernel_name(0).endswith("_r_jit"), plan.kernel_name(0)
+    assert rel_l2(out, from_complex(np.fft.fft(xr[..., 0].astype(np.float64), axis=1), np.float64)) < REL_L2_TOL_F32
+    x8 = rng.integers(0, 255, size=(21, 97, 2)).astype(np.uint8)
+    out, plan = _run(x8, out_dtype=torch.float32)
+    assert "_u8" in plan.kernel_name(0)
+    assert rel_l2(out, from_complex(np.fft.fft(to_complex(x8.astype(np.float64)), axis=1), np.float64)) < REL_L2_TOL_F32
+
+
 def test_lengths_outside_the_jit_stay_on_the_literal_stages():
     rng = np.random.default_rng(1)
-    x = rng.standard_normal((5, 97, 2)).astype(np.float32)    # prime > 31
-    out, plan = _run(x)
+    x = rng.standard_normal((5, 131, 2)).astype(np.float32)    # prime > 127
+    out, plan = _run(x, bases=[[131]])
     assert plan.kernel_name(0) == "generic"
-    assert rel_l2(out, O.fftn(x)) < REL_L2_TOL_F32
+    assert rel_l2(out, O.fftn(x, bases=[[131]])) < REL_L2_TOL_F32
+    xs = rng.standard_normal((2, 97, 20, 2)).astype(np.float32)   # strided dimension with a prime factor > 31
+    out, plan = _run(xs)
+    assert plan.kernel_name(0) == "generic"
 
 
 @pytest.mark.parametrize("in_dtype,comps", [(np.uint8, 1), (np.uint8, 2), (np.int32, 1), (np.int32, 2)])
