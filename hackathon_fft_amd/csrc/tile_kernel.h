@@ -445,7 +445,7 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
 
 // Pass 0 for a prime radix R > 32 (C::BIGP0), cooperatively in LDS.  The tile has been staged by the flat copy.
 //   1. in place: a_j = x_j + x_{R-j} at position j, b_j = x_j - x_{R-j} at position R-j   (j = 1..H, H = (R-1)/2)
-//   2. item (transform, butterfly, s), s = 0..H:  A = x_0 + sum_j cos(2 pi j s / R) a_j,  B = sum_j sin(2 pi j s / R) b_j
+//   2. per output pair s = 0..H (four consecutive s per thread):  A = x_0 + sum_j cos(2 pi j s / R) a_j,  B = sum_j sin(2 pi j s / R) b_j
 //      X_s = A - iB, X_{R-s} = A + iB  -- the conjugate-pair form of DftOddPrime, 4 real FMAs per (j, pair) instead of
 //      the 8 of the literal stage (fft/fft/_fft.mojo:261-290); lanes that share a butterfly read a_j, b_j as broadcasts
 //   3. after a barrier the outputs go to their Stockham positions b*R + s (pass 0: P = 1)
@@ -464,31 +464,47 @@ MIFFT_DEV void bigprime_pass0(cpx<typename C::T>* lds, const cpx<typename C::T>*
         lds[i2] = u - v;
     }
     __syncthreads();
-    constexpr int ITEMS = C::TILE * NB * (H + 1);
+    // item = (transform, butterfly, group of SB consecutive s): a_j and b_j are read once per j for SB output pairs
+    constexpr int SB = 4, GROUPS = (H + 1 + SB - 1) / SB;
+    constexpr int ITEMS = C::TILE * NB * GROUPS;
     constexpr int IPT = (ITEMS + C::THREADS - 1) / C::THREADS;
-    V lo[IPT], hi[IPT];
+    V lo[IPT][SB], hi[IPT][SB];
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         const int id = tid + k * C::THREADS;
         if (id < ITEMS) {
-            const int cb = id / (H + 1), s = id - cb * (H + 1);
+            const int cb = id / GROUPS, s0 = (id - cb * GROUPS) * SB;
             const int c = cb / NB, b = cb - c * NB;
             const V x0 = lds[lds_index<C, -1>(c, b)];
-            V A = x0, B = {(T)0, (T)0};
-            int m = 0;
+            V A[SB], B[SB];
+            int m[SB];
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                A[q] = x0;
+                B[q] = {(T)0, (T)0};
+                m[q] = 0;
+            }
 #pragma unroll 2
             for (int j = 1; j <= H; ++j) {
-                m += s;
-                if (m >= R) m -= R;
                 const V a = lds[lds_index<C, -1>(c, b + j * NB)], d = lds[lds_index<C, -1>(c, b + (R - j) * NB)];
-                const V w = cs[m];  // (cos, sin)(2 pi m / R)
-                A.x = fma_t(w.x, a.x, A.x);
-                A.y = fma_t(w.x, a.y, A.y);
-                B.x = fma_t(w.y, d.x, B.x);
-                B.y = fma_t(w.y, d.y, B.y);
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    // s0 + q may run past H in the last group: its index stays in range (s <= H + SB - 1 < R) and
+                    // its result is never stored
+                    m[q] += s0 + q;
+                    if (m[q] >= R) m[q] -= R;
+                    const V w = cs[m[q]];  // (cos, sin)(2 pi m / R)
+                    A[q].x = fma_t(w.x, a.x, A[q].x);
+                    A[q].y = fma_t(w.x, a.y, A[q].y);
+                    B[q].x = fma_t(w.y, d.x, B[q].x);
+                    B[q].y = fma_t(w.y, d.y, B[q].y);
+                }
             }
-            lo[k] = {A.x + B.y, A.y - B.x};  // X_s
-            hi[k] = {A.x - B.y, A.y + B.x};  // X_{R-s}
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                lo[k][q] = {A[q].x + B[q].y, A[q].y - B[q].x};  // X_s
+                hi[k][q] = {A[q].x - B[q].y, A[q].y + B[q].x};  // X_{R-s}
+            }
         }
     }
     __syncthreads();
@@ -496,10 +512,16 @@ MIFFT_DEV void bigprime_pass0(cpx<typename C::T>* lds, const cpx<typename C::T>*
     for (int k = 0; k < IPT; ++k) {
         const int id = tid + k * C::THREADS;
         if (id < ITEMS) {
-            const int cb = id / (H + 1), s = id - cb * (H + 1);
+            const int cb = id / GROUPS, s0 = (id - cb * GROUPS) * SB;
             const int c = cb / NB, b = cb - c * NB;
-            lds[lds_index<C, 0>(c, b * R + s)] = lo[k];
-            if (s > 0) lds[lds_index<C, 0>(c, b * R + R - s)] = hi[k];
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const int s = s0 + q;
+                if (s <= H) {
+                    lds[lds_index<C, 0>(c, b * R + s)] = lo[k][q];
+                    if (s > 0) lds[lds_index<C, 0>(c, b * R + R - s)] = hi[k][q];
+                }
+            }
         }
     }
     __syncthreads();
