@@ -173,10 +173,10 @@ struct TileCfg {
     // BIGP0: the first radix is a prime too large for a register butterfly (> 32).  Pass 0 then runs cooperatively in
     // LDS (bigprime_pass0): the row is staged by the flat copy, paired into sums / differences in place, and every
     // thread accumulates a few output pairs over the (R-1)/2 pairs with a cos/sin table of R entries kept behind the
-    // twiddle table.  Rows only; instantiated by the runtime-specialised kernels.
+    // twiddle table.  Instantiated by the runtime-specialised kernels only.
     static constexpr bool BIGP0 = R0_ > 32;
     static constexpr int CS_ELEMS = BIGP0 ? R0_ : 0;
-    static_assert(!BIGP0 || (!COLS_ && !FIRST_DIRECT_ && TWMODE_ == TW_LDS), "big-prime pass 0: flat-copied rows");
+    static_assert(!BIGP0 || (!FIRST_DIRECT_ && TWMODE_ == TW_LDS), "big-prime pass 0: tile staged in LDS first");
     // DMA: the flat HBM -> LDS copy of the NEXT tile runs asynchronously (global_load_lds) into a staging
     // buffer behind the twiddle table while this tile's passes execute
     static constexpr bool DMA = DMA_;
@@ -630,9 +630,25 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                 load_pass0<C>(p, pre, nbase, nnv, tid);
             }
         }
-        if constexpr (!C::FIRST_DIRECT) {
+        if constexpr (!C::FIRST_DIRECT && C::COLS) {
+            // column tile staged in LDS (only the big-prime pass 0 needs this): runs of TILE adjacent columns
+            static_assert(C::BIGP0, "column tiles load directly unless pass 0 works in LDS");
+            for (int f = tid; f < C::N * C::TILE; f += C::THREADS) {
+                const int n = f / C::TILE, c = f - n * C::TILE;
+                const int cc = c < nv ? c : nv - 1;  // ragged last tile: re-read a valid column, never stored
+                V x;
+                if constexpr (!same_t<typename C::IT, T>::value)
+                    x = load_foreign<C>(p.in, gaddr<C>(p, base, cc, n));
+                else if constexpr (C::IN_REAL)
+                    x = {gload_real<false>((const T*)p.in + gaddr<C>(p, base, cc, n)), (T)0};
+                else
+                    x = gload<false>((const V*)p.in + gaddr<C>(p, base, cc, n));
+                if (p.inverse) x.y = -x.y;
+                lds[lds_index<C, -1>(c, n)] = x;
+            }
+            __syncthreads();
+        } else if constexpr (!C::FIRST_DIRECT) {
             // flat, fully coalesced HBM -> LDS copy of the tile (rows need not be 16-B aligned: N = 93)
-            static_assert(!C::COLS || C::FIRST_DIRECT, "column tiles always load directly");
             const V* gin = (const V*)p.in;
             const int total = nv * C::N;
             {
@@ -737,8 +753,23 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                 }
             }
             __syncthreads();
+        } else if constexpr (!C::LAST_DIRECT && C::COLS) {
+            // a strided PRIME length (one cooperative pass, result in LDS): runs of TILE adjacent columns
+            static_assert(C::BIGP0 && C::NP == 1, "column tiles store directly unless the only pass works in LDS");
+            V* gout = (V*)p.out;
+            for (int f = tid; f < C::N * C::TILE; f += C::THREADS) {
+                const int n = f / C::TILE, c = f - n * C::TILE;
+                if (c < nv) {
+                    V y = lds[lds_index<C, C::NP - 1>(c, n)];
+                    if (p.inverse) {
+                        y.x *= (T)p.scale;
+                        y.y *= -(T)p.scale;
+                    }
+                    gout[gaddr<C>(p, base, c, n)] = y;
+                }
+            }
+            __syncthreads();
         } else if constexpr (!C::LAST_DIRECT) {
-            static_assert(!C::COLS || C::LAST_DIRECT, "column tiles always store directly");
             V* gout = (V*)p.out;
             const int total = nv * C::N;
             for (int f = tid; f < total; f += C::THREADS) {

@@ -110,6 +110,7 @@ def test_jit_precompile_needs_no_device():
     assert L.mifft_jit_precompile(0, 1, 93, 0, 0, ctypes.byref(sz)) == 0   # float input under a double plan
     assert L.mifft_jit_precompile(0, 0, 97, 0, 0, ctypes.byref(sz)) == 0    # one prime factor <= 127: cooperative pass 0
     assert L.mifft_jit_precompile(0, 0, 131, 0, 0, ctypes.byref(sz)) == -9
-    assert L.mifft_jit_precompile(0, 0, 97, 1, 0, ctypes.byref(sz)) == -9   # ... on contiguous dimensions only
+    assert L.mifft_jit_precompile(0, 0, 97, 1, 0, ctypes.byref(sz)) == 0    # ... strided too (tile staged in LDS)
+    assert L.mifft_jit_precompile(0, 0, 37 * 41, 0, 0, ctypes.byref(sz)) == -9   # two large prime factors
     assert b"fused" in L.mifft_last_error()
     assert L.mifft_jit_precompile(0, 5, 49, 0, 0, ctypes.byref(sz)) == -4

@@ -180,9 +180,23 @@ def test_lengths_outside_the_jit_stay_on_the_literal_stages():
     out, plan = _run(x, bases=[[131]])
     assert plan.kernel_name(0) == "generic"
     assert rel_l2(out, O.fftn(x, bases=[[131]])) < REL_L2_TOL_F32
-    xs = rng.standard_normal((2, 97, 20, 2)).astype(np.float32)   # strided dimension with a prime factor > 31
-    out, plan = _run(xs)
-    assert plan.kernel_name(0) == "generic"
+
+
+@pytest.mark.parametrize("n,inner,dtype", [(97, 20, np.float32), (74, 40, np.float32), (123, 16, np.float64),
+                                           (555, 33, np.float32), (37, 64, np.float32), (101, 24, np.float32)])
+def test_strided_dimension_with_a_large_prime_factor(n, inner, dtype):
+    """Column tiles stage their tile in LDS when pass 0 is the cooperative prime pass; a prime length also stores from
+    LDS (runs of TILE adjacent columns both ways)."""
+    rng = np.random.default_rng(n + inner)
+    x = rng.standard_normal((3, n, inner, 2)).astype(dtype)
+    bases = None if n != 101 else [[101], [2, 3]]
+    out, plan = _run(x, bases=bases)
+    assert plan.kernel_name(0).startswith("cols") and plan.kernel_name(0).endswith("_jit"), plan.kernel_name(0)
+    truth = np.fft.fftn(to_complex(x), axes=(1, 2))
+    tol = REL_L2_TOL_F32 if dtype == np.float32 else REL_L2_TOL_F64
+    assert rel_l2(out, from_complex(truth, np.float64)) < tol
+    back, _ = _run(out, inverse=True, bases=bases)
+    assert rel_l2(back, x) < tol
 
 
 @pytest.mark.parametrize("in_dtype,comps", [(np.uint8, 1), (np.uint8, 2), (np.int32, 1), (np.int32, 2)])
