@@ -114,3 +114,20 @@ def test_jit_precompile_needs_no_device():
     assert L.mifft_jit_precompile(0, 0, 37 * 41, 0, 0, ctypes.byref(sz)) == -9   # two large prime factors
     assert b"fused" in L.mifft_last_error()
     assert L.mifft_jit_precompile(0, 5, 49, 0, 0, ctypes.byref(sz)) == -4
+
+
+def test_jit_disk_cache_is_shared_between_processes(tmp_path):
+    """MIFFT_JIT_CACHE_DIR: the first process compiles and stores the code object, the second one loads it."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import ctypes, time, sys; sys.path.insert(0, %r); from hackathon_fft_amd import _lib; L = _lib.lib(); "
+            "sz = ctypes.c_size_t(); t = time.time(); rc = L.mifft_jit_precompile(0, 0, 363, 0, 0, ctypes.byref(sz)); "
+            "print(rc, sz.value, time.time() - t)" % ROOT)
+    env = dict(os.environ, MIFFT_JIT_CACHE_DIR=str(tmp_path))
+    first = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    files = list(tmp_path.glob("mifft_*.co"))
+    assert first[0] == "0" and len(files) == 1 and files[0].stat().st_size > 4096
+    second = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert second[:2] == first[:2]
+    assert float(second[2]) < 0.5 * float(first[2])      # loaded, not compiled
