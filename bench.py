@@ -46,6 +46,10 @@ WORKLOADS = {
     "2d_1x3840x2160": ((1, 3840, 2160), None, -1),
     "2d_1x7680x4320": ((1, 7680, 4320), None, -1),
     "1d_64x1048576_fourstep": ((64, 1 << 20), None, -1),
+    # lengths without a precompiled kernel: the tile kernel specialised at plan creation (hipRTC)
+    "1d_290kx343_radix7": ((290000, 343), None, -1),
+    "1d_330kx97_prime": ((330000, 97), None, -1),
+    "2d_3200x100x100_plane": ((3200, 100, 100), None, -1),
 }
 DEFAULT_WORKLOAD = "1d_100kx1024_radix2"
 
