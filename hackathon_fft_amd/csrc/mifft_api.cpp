@@ -243,6 +243,7 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
     auto upload_twiddles = [&](DimPass& ps) -> hipError_t {
         hipError_t e = upload_twiddle_table(out_dtype, ps.N, inverse != 0, &ps.d_twiddle);
         if (e == hipSuccess && ps.plane_needs_tw1) e = upload_twiddle_table(out_dtype, ps.N1, inverse != 0, &ps.d_aux);
+        if (e == hipSuccess && ps.needs_counters) e = hipMalloc(&ps.d_aux2, 16 * sizeof(unsigned));
         return e;
     };
     for (int i = ndim - 1; i >= 0; --i) {
@@ -265,7 +266,7 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                 pl.outer = 1;
                 for (int k = 0; k < i - 1; ++k) pl.outer *= dims[k];
                 std::string whyp;
-                if (select_fast_plane(p, pl) || select_jit_plane(p, pl, whyp)) {
+                if (select_fast_plane(p, pl) || select_jit_plane(p, pl, whyp) || select_jit_image(p, pl, whyp)) {
                     ps = pl;
                     ok = true;
                     --i;  // dimension i-1 is covered by this pass

@@ -65,6 +65,7 @@ struct DimPass {
     int src_buf = -1, dst_buf = -1;
     int64_t fs_n1 = 0, fs_n2 = 0;  // four-step factors of the dimension (transpose + twiddle pass)
     void* d_aux2 = nullptr;
+    bool needs_counters = false;      // image kernel: d_aux2 holds 16 unsigned counters, zeroed before every launch
     bool plane_needs_tw1 = false;     // rectangular fused plane: d_aux holds the W_N1 table of the column side
     void* jit_fn = nullptr;           // runtime-compiled kernel (hipFunction_t) of kernels_jit.cpp passes
     void* d_aux3 = nullptr;           // TSTORE passes: [tile][N] table of W^(c*k1) for the columns of one tile
@@ -100,6 +101,8 @@ bool select_jit(const Plan& plan, DimPass& pass, std::string& why_not);
 // feasibility predicates for scoring factorisations without compiling
 bool select_jit_streaming_rows(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_jit_plane(const Plan& plan, DimPass& pass, std::string& why_not);
+// the two innermost dimensions of images that fit one XCD's L2: rows, XCD-local barrier, columns from L2
+bool select_jit_image(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_jit_tstore(const Plan& plan, DimPass& pass, std::string& why_not);
 bool jit_tstore_feasible(const Plan& plan, int64_t n1, int64_t n2);
 bool jit_cols_feasible(const Plan& plan, int64_t n, int64_t inner);

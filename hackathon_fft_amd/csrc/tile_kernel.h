@@ -874,6 +874,117 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// image_kernel<CR, CC>: the two innermost dimensions (N1 x N2, N2 contiguous) of images that do NOT fit LDS but fit
+// one XCD's 4-MB L2 (100 x 640 x 480: 2.4 MB each).  Every XCD owns whole images: its workgroups transform the rows
+// of an image (x -> out, configuration CR), meet at an XCD-LOCAL barrier, and transform the columns in place
+// (configuration CC) while the row results are still in that XCD's L2 -- the column pass reads L2 instead of HBM, and
+// row results that are overwritten before they are evicted never reach HBM at all (guide: "each XCD has its own L2,
+// so make the blockIdx -> tile mapping XCD-aware").
+//   * XCD of a workgroup: the hardware XCC_ID register, not an assumption about the dispatch order; the slot inside the
+//     XCD is a ticket from an atomic counter that lives in that XCD's L2.
+//   * barrier: one arrival counter per XCD, relaxed agent-scope atomics (executed in the L2 all participants share).
+//     The stores of a phase are complete in L2 before the arrival is counted (__syncthreads() drains vmcnt); an
+//     agent-scope RELEASE fence is deliberately not used -- on gfx942/950 it writes the L2 back to HBM.
+//   * every spin is bounded (a dispatch that does not give each XCD its workgroups ends with a wrong result instead of
+//     a hang); the host probes the XCC_ID distribution of the same launch geometry at plan time before it selects this
+//     kernel (kernels_jit.cpp).
+// Launch: 8 * wgs_per_xcd workgroups, all resident (one per CU); counters zeroed before every launch.
+// ---------------------------------------------------------------------------------------------
+struct ImageParams {
+    const void* in;
+    void* out;
+    const void* tw_rows;  // W_N2
+    const void* tw_cols;  // W_N1
+    long long n_images;
+    unsigned* counters;  // [0..7] tickets, [8..15] arrivals
+    int wgs_per_xcd;
+    int inverse;
+};
+
+MIFFT_DEV unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+
+MIFFT_DEV void xcd_barrier(unsigned* arrive, unsigned target, int tid) {
+    __syncthreads();  // workgroup-scope release: every wave's global stores of the phase are complete in L2
+    if (tid == 0) {
+        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 20))
+            __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's L1 lines; nothing is written back
+}
+
+template <class CR, class CC>
+__global__ __launch_bounds__(CR::THREADS, 1) void image_kernel(const ImageParams q) {
+    using T = typename CR::T;
+    using V = cpx<T>;
+    static_assert(!CR::COLS && CC::COLS && CR::THREADS == CC::THREADS, "rows configuration, columns configuration");
+    static_assert(CR::FIRST_DIRECT && CR::LAST_DIRECT && CC::FIRST_DIRECT && CC::LAST_DIRECT, "direct tiles");
+    static_assert(CR::TWMODE == TW_LDS && CC::TWMODE == TW_LDS && !CR::PREFETCH && !CC::PREFETCH, "LDS twiddles");
+    static_assert(!CR::BIGP0 && !CC::BIGP0 && !CC::TSTORE, "register butterflies only");
+    constexpr int MAXD = CR::DATA_ELEMS > CC::DATA_ELEMS ? CR::DATA_ELEMS : CC::DATA_ELEMS;
+    constexpr int TWS_R = MAXD - CR::DATA_ELEMS, TWS_C = MAXD + CR::TWL_TOTAL - CC::DATA_ELEMS;
+    constexpr size_t IMAGE_LDS = (size_t)(MAXD + CR::TWL_TOTAL + CC::TWL_TOTAL) * sizeof(V);
+    static_assert(IMAGE_LDS <= 160 * 1024, "tiles + both twiddle tables must fit LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[IMAGE_LDS];
+    __shared__ unsigned s_slot;
+    V* lds = (V*)smem;
+    const int tid0 = threadIdx.x;
+    constexpr long long N1 = CC::N, N2 = CR::N;
+
+    fill_lds_tw<CR, 1>(lds + MAXD, (const V*)q.tw_rows, tid0, q.inverse);
+    fill_lds_tw<CC, 1>(lds + MAXD + CR::TWL_TOTAL, (const V*)q.tw_cols, tid0, q.inverse);
+    const unsigned xcc = xcc_id() & 7;
+    if (tid0 == 0) s_slot = __hip_atomic_fetch_add(q.counters + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const long long slot = s_slot, W = q.wgs_per_xcd;
+    unsigned* arrive = q.counters + 8 + xcc;
+    if (slot >= W) return;  // more workgroups on this XCD than planned: they take no part (the probe rules this out)
+
+    TileParams pr{}, pc{};
+    pr.in = q.in;
+    pr.out = q.out;
+    pr.tw = q.tw_rows;
+    pr.inner = 1;
+    pr.inverse = q.inverse;
+    pr.scale = q.inverse ? 1.0 / (double)N2 : 1.0;
+    pc.in = q.out;
+    pc.out = q.out;
+    pc.tw = q.tw_cols;
+    pc.inner = N2;
+    pc.inverse = q.inverse;
+    pc.scale = q.inverse ? 1.0 / (double)N1 : 1.0;
+    constexpr long long TILES_R = (N1 + CR::TILE - 1) / CR::TILE, TILES_C = (N2 + CC::TILE - 1) / CC::TILE;
+    V twr[1];
+    V none_r[1][CR::R(0)], none_c[1][CC::R(0)];
+    unsigned phase = 0;
+    for (long long img = xcc; img < q.n_images; img += 8) {
+        const long long ibase = img * N1 * N2;
+        for (long long tr = slot; tr < TILES_R; tr += W) {  // rows of this image: x -> out
+            int tid = tid0;
+            asm volatile("" : "+v"(tid));
+            const long long left = N1 - tr * CR::TILE;
+            run_pass<CR, 0, TWS_R>(pr, lds, twr, none_r, ibase + tr * CR::TILE * N2, (int)(left < CR::TILE ? left : CR::TILE), tid);
+            __syncthreads();
+        }
+        xcd_barrier(arrive, (unsigned)((++phase) * W), tid0);
+        for (long long tc = slot; tc < TILES_C; tc += W) {  // columns, in place, from this XCD's L2
+            int tid = tid0;
+            asm volatile("" : "+v"(tid));
+            const long long left = N2 - tc * CC::TILE;
+            run_pass<CC, 0, TWS_C>(pc, lds, twr, none_c, ibase + tc * CC::TILE, (int)(left < CC::TILE ? left : CC::TILE), tid);
+            __syncthreads();
+        }
+        // no barrier here: the next image is other memory, and every workgroup still arrives exactly once per barrier
+    }
+}
+
 // persistent grid: enough workgroups to fill every CU to its LDS / wave limit
 template <class C>
 inline long long tile_grid(int num_cus, long long n_tiles, int wg_per_cu_override = 0) {
