@@ -253,8 +253,17 @@ def _cached_plan(in_dtype, out_dtype, in_shape, out_shape, radices, inverse, fai
            bool(inverse), bool(faithful_stages), device)
     plan = _PLAN_CACHE.get(key)
     if plan is None:
-        plan = plan_fft(in_dtype, out_dtype, in_shape, out_shape, bases=radices, inverse=inverse,
-                        faithful_stages=faithful_stages, ctx=DeviceContext(device))
+        try:
+            plan = plan_fft(in_dtype, out_dtype, in_shape, out_shape, bases=radices, inverse=inverse,
+                            faithful_stages=faithful_stages, ctx=DeviceContext(device))
+        except MifftError as e:
+            # plan_fft keeps the reference's behaviour: its default radix estimate (trial division by 2..32 on the GPU,
+            # primes <= 97 otherwise, fft/fft/fft.mojo:49-104) rejects lengths with a larger prime factor.  The
+            # numpy-style wrappers are this repository's own surface, so they retry with the full prime factorisation.
+            if radices is not None or e.status not in (-5, -7):
+                raise
+            plan = plan_fft(in_dtype, out_dtype, in_shape, out_shape, bases=[_prime_factors(int(n)) for n in in_shape[1:-1]],
+                            inverse=inverse, faithful_stages=faithful_stages, ctx=DeviceContext(device))
         _PLAN_CACHE[key] = plan
         while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
             _, old = _PLAN_CACHE.popitem(last=False)
@@ -263,6 +272,20 @@ def _cached_plan(in_dtype, out_dtype, in_shape, out_shape, radices, inverse, fai
     else:
         _PLAN_CACHE.move_to_end(key)
     return plan
+
+
+def _prime_factors(n: int) -> list:
+    """distinct prime factors of n, ascending (a complete `bases` list for any length)"""
+    f, d = [], 2
+    while d * d <= n:
+        if n % d == 0:
+            f.append(d)
+            while n % d == 0:
+                n //= d
+        d += 1
+    if n > 1:
+        f.append(n)
+    return f
 
 
 def clear_plan_cache() -> None:

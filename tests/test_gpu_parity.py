@@ -204,6 +204,20 @@ def test_errors_from_the_device_side_of_the_boundary():
     assert e.value.status == -9            # beyond four-step reach (4096 x 4096 points)
 
 
+def test_convenience_wrappers_accept_any_length():
+    """plan_fft rejects lengths its (reference) default radices cannot factor; fftn / ifftn / rfftn retry with the full
+    prime factorisation, numpy-style."""
+    rng = np.random.default_rng(4)
+    for shape in [(3, 634), (2, 131, 6), (2, 1009)]:          # 2 * 317, prime 131, prime 1009
+        xc = torch.from_numpy(rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).to(DEV)
+        with pytest.raises(mf.MifftError):
+            mf.plan_fft(torch.float64, torch.float64, tuple(shape) + (2,), tuple(shape) + (2,))
+        y = mf.fftn(xc)
+        np.testing.assert_allclose(y.cpu().numpy(), np.fft.fftn(xc.cpu().numpy(), axes=tuple(range(1, len(shape)))),
+                                   atol=1e-9)
+        np.testing.assert_allclose(mf.ifftn(y).cpu().numpy(), xc.cpu().numpy(), atol=1e-11)
+
+
 def test_convenience_wrappers():
     rng = np.random.default_rng(2)
     xc = torch.from_numpy(rng.standard_normal((3, 16, 12)) + 1j * rng.standard_normal((3, 16, 12))).to(DEV)
