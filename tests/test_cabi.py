@@ -96,7 +96,7 @@ def test_python_layout_checks_mirror_reference():
 
 def test_jit_precompile_needs_no_device():
     """hipRTC builds the runtime-specialised kernel on a machine without a GPU (the code object is only loaded at
-    plan creation); a prime factor above 1021 has no fused configuration."""
+    plan creation); a prime factor above 4093 has no fused configuration."""
     import ctypes
     from hackathon_fft_amd import _lib
     L = _lib.lib()
@@ -108,8 +108,8 @@ def test_jit_precompile_needs_no_device():
     assert L.mifft_jit_precompile(2, 0, 480, 0, 1, ctypes.byref(sz)) == 0  # uint8 real input widened in the load
     assert L.mifft_jit_precompile(3, 0, 96, 0, 0, ctypes.byref(sz)) == 0   # int32 complex input
     assert L.mifft_jit_precompile(0, 1, 93, 0, 0, ctypes.byref(sz)) == 0   # float input under a double plan
-    assert L.mifft_jit_precompile(0, 0, 97, 0, 0, ctypes.byref(sz)) == 0    # one prime factor <= 1021: cooperative pass 0
-    assert L.mifft_jit_precompile(0, 0, 1031, 0, 0, ctypes.byref(sz)) == -9
+    assert L.mifft_jit_precompile(0, 0, 97, 0, 0, ctypes.byref(sz)) == 0    # one prime factor <= 4093: cooperative pass 0
+    assert L.mifft_jit_precompile(0, 0, 4099, 0, 0, ctypes.byref(sz)) == -9
     assert L.mifft_jit_precompile(0, 0, 97, 1, 0, ctypes.byref(sz)) == 0    # ... strided too (tile staged in LDS)
     assert L.mifft_jit_precompile(0, 0, 37 * 41, 0, 0, ctypes.byref(sz)) == -9   # two large prime factors
     assert b"fused" in L.mifft_last_error()

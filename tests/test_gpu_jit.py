@@ -127,9 +127,9 @@ def test_results_do_not_depend_on_the_tile_slot_jit():
         assert np.array_equal(out[i], out[0]), i
 
 
-# lengths with ONE prime factor in (31, 1021]: that factor is pass 0, run cooperatively in LDS (TileCfg::BIGP0)
+# lengths with ONE prime factor in (31, 4093]: that factor is pass 0, run cooperatively in LDS (TileCfg::BIGP0)
 BIG_PRIME_ROWS = [97, 37, 74, 123, 127, 194, 101, 113, 122, 555, 328, 89 * 12, 4 * 9 * 43, 131, 251, 509, 1009, 1021,
-                  2 * 251, 3 * 337]
+                  2 * 251, 3 * 337, 2039, 4093]
 
 
 @pytest.mark.parametrize("n", BIG_PRIME_ROWS)
@@ -177,8 +177,8 @@ def test_large_prime_factor_fp64_and_real_and_uint8():
 
 def test_lengths_outside_the_jit_stay_on_the_literal_stages():
     rng = np.random.default_rng(1)
-    x = rng.standard_normal((5, 1031, 2)).astype(np.float32)    # prime > 1021
-    out, plan = _run(x, bases=[[1031]])
+    x = rng.standard_normal((5, 4099, 2)).astype(np.float32)    # prime > 4093
+    out, plan = _run(x, bases=[[4099]])
     assert plan.kernel_name(0) == "generic"
     assert rel_l2(out, from_complex(np.fft.fft(to_complex(x), axis=1), np.float64)) < REL_L2_TOL_F32
     x = rng.standard_normal((5, 37 * 41, 2)).astype(np.float32)  # two prime factors > 31

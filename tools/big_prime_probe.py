@@ -1,7 +1,7 @@
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch, hackathon_fft_amd as mf
-for n in (131, 251, 509, 1009, 2 * 251, 3 * 337):
+for n in (131, 251, 509, 1009, 2 * 251, 3 * 337, 2039, 4093, 2 * 2039, 5 * 1021):
     batch = max(1, int(64e6 / (n * 8)))
     x = torch.randn((batch, n, 2), device="cuda:0"); out = torch.empty_like(x)
     f, m, d = [], n, 2
