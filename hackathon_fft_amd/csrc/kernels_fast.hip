@@ -167,7 +167,8 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols || e.tstore) return false;
         if (e.in_real != (pass.first && plan.in_components == 1)) return false;
         if (e.stream_pref == 1 && !streaming) return false;
-        if (cols && pass.inner < e.tile) return false;
+        // (a strided dimension with fewer columns than one tile still runs here: the ragged tile clamps its loads and
+        //  masks its stores; the literal-stage alternative is an order of magnitude slower)
         pass.kernel_name = e.name;
         pass.launch = e.launch;
         pass.prepare = e.prepare;

@@ -204,6 +204,20 @@ def test_errors_from_the_device_side_of_the_boundary():
     assert e.value.status == -9            # beyond four-step reach (4096 x 4096 points)
 
 
+@pytest.mark.parametrize("shape", [(7, 1024, 3), (5, 640, 8), (3, 128, 5, 2), (4, 343, 7), (9, 64, 2), (6, 97, 3)])
+def test_strided_dimension_with_fewer_columns_than_a_tile(shape):
+    """A transformed dimension in front of a very short one (3 channels, 2 components): the 16-column tile is ragged from
+    the start, and still the fused kernels run (not the literal stages)."""
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape + (2,)).astype(np.float32)
+    out, plan = gpu_fft(x, out_dtype=np.float32)
+    assert plan.kernel_name(0) != "generic", [plan.kernel_name(d) for d in range(len(shape) - 1)]
+    truth = np.fft.fftn(to_complex(x), axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
+    back, _ = gpu_fft(out, inverse=True, out_dtype=np.float32)
+    assert rel_l2(back, x) < REL_L2_TOL_F32
+
+
 def test_convenience_wrappers_accept_any_length():
     """plan_fft rejects lengths its (reference) default radices cannot factor; fftn / ifftn / rfftn retry with the full
     prime factorisation, numpy-style."""
