@@ -62,6 +62,8 @@ for i in range(cases):
         fam[cat] += 1
         continue
     names = [plan.kernel_name(d) for d in range(nd)]
+    if "generic" in names and os.environ.get("FUZZ_SHOW_GENERIC"):
+        print(f"generic: {shape} batch {batch} {kind} {out_dt.__name__} {names}")
     for nm in set(names):
         key = "generic" if nm == "generic" else "jit" if nm.endswith("_jit") else "transpose" if nm == "transpose" else "table"
         if "_ts" in nm:
