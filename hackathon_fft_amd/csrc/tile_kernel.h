@@ -187,7 +187,12 @@ struct TileCfg {
     // thread accumulates a few output pairs over the (R-1)/2 pairs with a cos/sin table of R entries kept behind the
     // twiddle table.  Instantiated by the runtime-specialised kernels only.
     static constexpr bool BIGP0 = R0_ > 32;
-    static constexpr int CS_ELEMS = BIGP0 ? R0_ : 0;
+    // a second prime above 32 is pass 1 (its inputs are twiddled while they are paired)
+    static constexpr bool BIGP1 = NP_ > 1 && R1_ > 32;
+    static_assert(!(R2_ > 32 || R3_ > 32) && (!BIGP1 || BIGP0), "cooperative passes come first, at most two");
+    static constexpr bool BIGP(int i) { return i == 0 ? BIGP0 : i == 1 ? BIGP1 : false; }
+    static constexpr int CS_OFF(int i) { return i == 0 ? 0 : (BIGP0 ? R0_ : 0); }
+    static constexpr int CS_ELEMS = (BIGP0 ? R0_ : 0) + (BIGP1 ? R1_ : 0);
     static_assert(!BIGP0 || (!FIRST_DIRECT_ && TWMODE_ == TW_LDS), "big-prime pass 0: tile staged in LDS first");
     // DMA: the flat HBM -> LDS copy of the NEXT tile runs asynchronously (global_load_lds) into a staging
     // buffer behind the twiddle table while this tile's passes execute
@@ -455,23 +460,30 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
     }
 }
 
-// Pass 0 for a prime radix R > 32 (C::BIGP0), cooperatively in LDS.  The tile has been staged by the flat copy.
+// A pass with a prime radix R > 32 (C::BIGP(I)), cooperatively in LDS.  The tile is in LDS (pass 0: staged by the copy).
 //   1. in place: a_j = x_j + x_{R-j} at position j, b_j = x_j - x_{R-j} at position R-j   (j = 1..H, H = (R-1)/2)
 //   2. per output pair s = 0..H (four consecutive s per thread):  A = x_0 + sum_j cos(2 pi j s / R) a_j,  B = sum_j sin(2 pi j s / R) b_j
 //      X_s = A - iB, X_{R-s} = A + iB  -- the conjugate-pair form of DftOddPrime, 4 real FMAs per (j, pair) instead of
 //      the 8 of the literal stage (fft/fft/_fft.mojo:261-290); lanes that share a butterfly read a_j, b_j as broadcasts
-//   3. after a barrier the outputs go to their Stockham positions b*R + s (pass 0: P = 1)
-template <class C>
-MIFFT_DEV void bigprime_pass0(cpx<typename C::T>* lds, const cpx<typename C::T>* cs, int tid) {
+//   3. after a barrier the outputs go to their Stockham positions
+//   (pass I >= 1: the inputs x_j are first multiplied by their Stockham twiddles W_{P R}^{j p} from the LDS table, and
+//    the outputs go to q*P*R + p + s*P)
+template <class C, int I>
+MIFFT_DEV void bigprime_pass(cpx<typename C::T>* lds, const cpx<typename C::T>* ltw, const cpx<typename C::T>* cs, int tid) {
     using T = typename C::T;
     using V = cpx<T>;
-    constexpr int R = C::R(0), H = (R - 1) / 2, NB = C::NB(0);
+    constexpr int R = C::R(I), H = (R - 1) / 2, NB = C::NB(I), P = C::P(I);
     constexpr int PAIRS = C::TILE * NB * H;
     for (int e = tid; e < PAIRS; e += C::THREADS) {
         const int c = e / (NB * H), rem = e - c * (NB * H);
         const int b = rem / H, j = rem - b * H + 1;
-        const int i1 = lds_index<C, -1>(c, b + j * NB), i2 = lds_index<C, -1>(c, b + (R - j) * NB);
-        const V u = lds[i1], v = lds[i2];
+        const int i1 = lds_index<C, I - 1>(c, b + j * NB), i2 = lds_index<C, I - 1>(c, b + (R - j) * NB);
+        V u = lds[i1], v = lds[i2];
+        if constexpr (I > 0) {
+            const int pp = b % P;
+            u = cmul(u, ltw[C::TWL_OFF(I) + (j - 1) * P + pp]);
+            v = cmul(v, ltw[C::TWL_OFF(I) + (R - j - 1) * P + pp]);
+        }
         lds[i1] = u + v;
         lds[i2] = u - v;
     }
@@ -487,7 +499,7 @@ MIFFT_DEV void bigprime_pass0(cpx<typename C::T>* lds, const cpx<typename C::T>*
         if (id < ITEMS) {
             const int cb = id / GROUPS, s0 = (id - cb * GROUPS) * SB;
             const int c = cb / NB, b = cb - c * NB;
-            const V x0 = lds[lds_index<C, -1>(c, b)];
+            const V x0 = lds[lds_index<C, I - 1>(c, b)];
             V A[SB], B[SB];
             int m[SB];
 #pragma unroll
@@ -498,7 +510,7 @@ MIFFT_DEV void bigprime_pass0(cpx<typename C::T>* lds, const cpx<typename C::T>*
             }
 #pragma unroll 2
             for (int j = 1; j <= H; ++j) {
-                const V a = lds[lds_index<C, -1>(c, b + j * NB)], d = lds[lds_index<C, -1>(c, b + (R - j) * NB)];
+                const V a = lds[lds_index<C, I - 1>(c, b + j * NB)], d = lds[lds_index<C, I - 1>(c, b + (R - j) * NB)];
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     // s0 + q may run past H in the last group: its index stays in range (s <= H + SB - 1 < R) and
@@ -530,8 +542,9 @@ MIFFT_DEV void bigprime_pass0(cpx<typename C::T>* lds, const cpx<typename C::T>*
             for (int q = 0; q < SB; ++q) {
                 const int s = s0 + q;
                 if (s <= H) {
-                    lds[lds_index<C, 0>(c, b * R + s)] = lo[k][q];
-                    if (s > 0) lds[lds_index<C, 0>(c, b * R + R - s)] = hi[k][q];
+                    const int qq = b / P, o0 = qq * P * R + (b - qq * P);  // Stockham scatter (pass 0: P = 1)
+                    lds[lds_index<C, I>(c, o0 + s * P)] = lo[k][q];
+                    if (s > 0) lds[lds_index<C, I>(c, o0 + (R - s) * P)] = hi[k][q];
                 }
             }
         }
@@ -543,9 +556,9 @@ MIFFT_DEV void bigprime_pass0(cpx<typename C::T>* lds, const cpx<typename C::T>*
 template <class C, int I, int TWSHIFT = 0>
 MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<typename C::T>* twr,
                         cpx<typename C::T> (*pre)[C::R(0)], long long base, int nv, int tid) {
-    if constexpr (I == 0 && C::BIGP0) {
-        bigprime_pass0<C>(lds, lds + C::DATA_ELEMS + C::TWL_TOTAL, tid);
-        run_pass<C, 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid);
+    if constexpr (I < C::NP && C::BIGP(I)) {
+        bigprime_pass<C, I>(lds, lds + C::DATA_ELEMS + TWSHIFT, lds + C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(I), tid);
+        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid);
     } else if constexpr (I < C::NP) {
         using T = typename C::T;
         using V = cpx<T>;
@@ -600,6 +613,13 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                 V w = ((const V*)p.tw)[m * C::NB(0)];
                 if (p.inverse) w.y = -w.y;
                 lds[C::DATA_ELEMS + C::TWL_TOTAL + m] = {w.x, -w.y};
+            }
+        }
+        if constexpr (C::BIGP1) {
+            for (int m = tid0; m < C::R(1); m += C::THREADS) {
+                V w = ((const V*)p.tw)[m * C::NB(1)];
+                if (p.inverse) w.y = -w.y;
+                lds[C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(1) + m] = {w.x, -w.y};
             }
         }
         __syncthreads();
@@ -776,7 +796,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             __syncthreads();
         } else if constexpr (!C::LAST_DIRECT && C::COLS) {
             // a strided PRIME length (one cooperative pass, result in LDS): runs of TILE adjacent columns
-            static_assert(C::BIGP0 && C::NP == 1, "column tiles store directly unless the only pass works in LDS");
+            static_assert(C::BIGP(C::NP - 1), "column tiles store directly unless the last pass works in LDS");
             V* gout = (V*)p.out;
             for (int f = tid; f < C::N * C::TILE; f += C::THREADS) {
                 const int n = f / C::TILE, c = f - n * C::TILE;

@@ -189,7 +189,7 @@ int mifft_time_exec(const mifft_plan* plan, const void* x, void* out, void* stre
  * length x length plane (two innermost dimensions in one LDS tile), k >= 8 a fused k x length plane (length = the
  * contiguous side); real_input != 0: the C_in = 1 twin.
  * Returns MIFFT_OK, or MIFFT_ERR_TOO_LARGE when the length has no fused configuration (a prime factor above 4093,
- * two prime factors above 31, or a tile beyond the 160 KiB of LDS) -- such lengths run on the literal-stage kernels.
+ * three prime factors above 31, or a tile beyond the 160 KiB of LDS) -- such lengths run on the literal-stage kernels.
  */
 int mifft_jit_precompile(int in_dtype, int out_dtype, int64_t length, int strided, int real_input,
                          size_t* code_bytes_out);

@@ -111,7 +111,8 @@ def test_jit_precompile_needs_no_device():
     assert L.mifft_jit_precompile(0, 0, 97, 0, 0, ctypes.byref(sz)) == 0    # one prime factor <= 4093: cooperative pass 0
     assert L.mifft_jit_precompile(0, 0, 4099, 0, 0, ctypes.byref(sz)) == -9
     assert L.mifft_jit_precompile(0, 0, 97, 1, 0, ctypes.byref(sz)) == 0    # ... strided too (tile staged in LDS)
-    assert L.mifft_jit_precompile(0, 0, 37 * 41, 0, 0, ctypes.byref(sz)) == -9   # two large prime factors
+    assert L.mifft_jit_precompile(0, 0, 37 * 41, 0, 0, ctypes.byref(sz)) == 0    # two large prime factors: passes 0 and 1
+    assert L.mifft_jit_precompile(0, 0, 37 * 41 * 43, 0, 0, ctypes.byref(sz)) == -9   # three
     assert b"fused" in L.mifft_last_error()
     assert L.mifft_jit_precompile(0, 5, 49, 0, 0, ctypes.byref(sz)) == -4
 

@@ -129,7 +129,8 @@ def test_results_do_not_depend_on_the_tile_slot_jit():
 
 # lengths with ONE prime factor in (31, 4093]: that factor is pass 0, run cooperatively in LDS (TileCfg::BIGP0)
 BIG_PRIME_ROWS = [97, 37, 74, 123, 127, 194, 101, 113, 122, 555, 328, 89 * 12, 4 * 9 * 43, 131, 251, 509, 1009, 1021,
-                  2 * 251, 3 * 337, 2039, 4093]
+                  2 * 251, 3 * 337, 2039, 4093,
+                  37 * 41, 41 * 53, 59 * 73, 2 * 37 * 41, 3 * 43 * 47]   # two primes above 31: passes 0 and 1
 
 
 @pytest.mark.parametrize("n", BIG_PRIME_ROWS)
@@ -181,13 +182,14 @@ def test_lengths_outside_the_jit_stay_on_the_literal_stages():
     out, plan = _run(x, bases=[[4099]])
     assert plan.kernel_name(0) == "generic"
     assert rel_l2(out, from_complex(np.fft.fft(to_complex(x), axis=1), np.float64)) < REL_L2_TOL_F32
-    x = rng.standard_normal((5, 37 * 41, 2)).astype(np.float32)  # two prime factors > 31
-    out, plan = _run(x, bases=[[41, 37]])
-    assert plan.kernel_name(0) == "generic"
-    assert rel_l2(out, from_complex(np.fft.fft(to_complex(x), axis=1), np.float64)) < REL_L2_TOL_F32
+    x = rng.standard_normal((3, 37 * 41 * 5, 4, 2)).astype(np.float32)  # strided, two prime factors > 31, more passes
+    out, plan = _run(x, bases=[[41, 37, 5], [2]])
+    truth = np.fft.fftn(to_complex(x), axes=(1, 2))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
 
 
 @pytest.mark.parametrize("n,inner,dtype", [(97, 20, np.float32), (74, 40, np.float32), (123, 16, np.float64),
+                                           (37 * 41, 24, np.float32), (2 * 37 * 43, 16, np.float32),
                                            (555, 33, np.float32), (37, 64, np.float32), (101, 24, np.float32)])
 def test_strided_dimension_with_a_large_prime_factor(n, inner, dtype):
     """Column tiles stage their tile in LDS when pass 0 is the cooperative prime pass; a prime length also stores from
