@@ -108,6 +108,22 @@ def test_planes_are_fused(shape, dtype, comps):
         assert rel_l2(back, x) < tol
 
 
+@pytest.mark.parametrize("n,dtype", [(4984, np.float64), (6000, np.float64), (8192, np.float64), (10000, np.float32),
+                                     (15625, np.float32), (12000, np.float32)])
+def test_long_rows_one_per_workgroup(n, dtype):
+    """Rows of up to 128 KiB (16384 points fp32, 8192 fp64) without a table entry: one row per workgroup, twiddles
+    from the global table when the LDS table no longer fits."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((5, n, 2)).astype(dtype)
+    out, plan = _run(x)
+    assert plan.kernel_name(0).endswith("_jit") and plan.num_launches == 1, plan.kernel_name(0)
+    truth = np.fft.fft(to_complex(x), axis=1)
+    tol = REL_L2_TOL_F32 if dtype == np.float32 else 1e-11
+    assert rel_l2(out, from_complex(truth, np.float64)) < tol
+    back, _ = _run(out, inverse=True)
+    assert rel_l2(back, x) < tol
+
+
 def test_mixed_nd_with_a_jit_dimension():
     rng = np.random.default_rng(5)
     x = rng.standard_normal((2, 49, 12, 121, 2)).astype(np.float32)
