@@ -291,7 +291,8 @@ bool build_transposed_dim(Plan& plan, int dim_index, const std::vector<uint32_t>
     rows.radices = radices;
     rows.processed = processed;
     rows.first = false;
-    if (!select_fast(plan, rows) && !select_generic(plan, rows, why_not)) return false;
+    std::string whyj;
+    if (!select_fast(plan, rows) && !select_jit(plan, rows, whyj) && !select_generic(plan, rows, why_not)) return false;
     rows.src_buf = 2;
     rows.dst_buf = 2;
     DimPass t_in, t_out;

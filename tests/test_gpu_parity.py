@@ -375,7 +375,7 @@ def test_four_step_on_the_contiguous_dimension_of_an_nd_transform(shape, comps):
         assert rel_l2(back, x) < REL_L2_TOL_F32
 
 
-@pytest.mark.parametrize("shape", [(1, 7680, 64), (2, 5120, 40), (1, 8192, 3, 5), (1, 6144, 100)])
+@pytest.mark.parametrize("shape", [(1, 7680, 64), (2, 5120, 40), (1, 8192, 3, 5), (1, 6144, 100), (2, 5000, 24), (1, 9000, 10)])
 def test_long_strided_dimension_through_transposes(shape):
     """A strided dimension beyond the column-tile table (8K-video columns): transpose -> row kernel -> transpose
     through the plan scratch."""
