@@ -1,27 +1,41 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on BASELINE.json's config, on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--scaling weak|strong]
 
-A "step" is one pass of the hot path (one plan_fft'd `fft(out, x)` call) over one batch of
-synthetic complex64 input that is already resident in HBM.  At N=1 the workload is
-BASELINE.json configs[1]: 100k x 1024 1-D C2C fp32 with the user radix list [2]
-("radix-2 Stockham").  For N>1 every rank owns its own 100k x 1024 slab (weak scaling, no
-data-path collective: rows are independent transforms); value = rows of all ranks * FLOPs / the
-max-over-ranks time.
+A "step" is one pass of the hot path (one plan_fft'd `fft(out, x)` call) over one batch of synthetic complex64 input
+that is already resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: 100k x 1024 1-D C2C fp32 with the
+user radix list [2] ("radix-2 Stockham").
+
+Multi-GPU: one process per GPU.  Started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) this
+process spawns the N ranks itself -- before torch or HIP is touched, each rank a fresh child process -- and relays rank
+0's JSON line; started under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one of
+the ranks.  Either way WORLD_SIZE must equal --gpus, and `ranks_seen` (an all-reduce of ones over RCCL) is printed.
+  --scaling weak   (default) every rank owns its own 100k x 1024 slab, no data-path collective: value = rows of all
+                   ranks * FLOPs / max-over-ranks time
+  --scaling strong BASELINE configs[4]: ONE 10 x 128^3 batch split over the ranks (2,2,1,..,1 volumes at N=8: the ideal
+                   speed-up is 5x, 3.33x at N=4, 2x at N=2); "compute, shards resident" and "end-to-end incl. the
+                   scatter/gather of ShardedFFT.fft_from_root over RCCL" are reported separately
+The default run also carries the strong-scaling leg as the object `strong_config5`.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      HBM roofline of the dominant kernel; `achieved` = algorithmic bytes per launch
-                (16 B per complex element: one 8-B read + one 8-B write) divided by
-                the average launch duration measured with HIP events on the launch stream inside
-                libmifft (mifft_time_exec).
-  cpu_baseline  the CPU oracle (restatement of the reference's multi-threaded CPU path) timed on
-                this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline       HBM roofline of the dominant kernel; `achieved` = algorithmic bytes per launch (16 B per complex element:
+                 one 8-B read + one 8-B write) / the average launch duration measured with HIP events on
+                 the launch stream inside libmifft (mifft_time_exec)
+  ramp           the untimed clock / cache ramp that precedes the W warm-up steps (ms, execs)
+  configs        (N=1) the other four BASELINE.json configs, each timed the same way in this run
+  cpu_baseline   (N=1) the CPU oracle (restatement of the reference's multi-threaded CPU path) on this host's cores on a
+                 bounded sample of the workload, with its 1-thread figure and the SciPy / NumPy comparators of the
+                 reference's benchmark-cpu-others/benchmark.py beside it
+  vendor_rocfft  (N=1, when tools/vendor_fft_bench is built) bench-only comparator column: rocFFT on the five BASELINE
+                 shapes, in its own process (the analogue of the reference's cuFFT harness); never part of libmifft
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+METRIC = "C2C GFLOP/s (5Nlog2N) + ms/transform, 100k×1024 fp32 @1/2/4/8 MI355X"
 
 WORKLOADS = {
     # name: (shape without the complex dim, user bases, BASELINE.json config index)
@@ -52,6 +67,10 @@ WORKLOADS = {
     "2d_3200x100x100_plane": ((3200, 100, 100), None, -1),
 }
 DEFAULT_WORKLOAD = "1d_100kx1024_radix2"
+STRONG_WORKLOAD = "3d_10x128x128x128"
+# the BASELINE.json configs other than the headline, in index order (the `configs` array of the N=1 line)
+OTHER_BASELINE_CONFIGS = ["1d_500kx128", "1d_500kx93_radix31x3", "2d_100x640x480", "3d_10x128x128x128"]
+RAMP_S = 0.05
 
 
 def flops_5nlogn(shape):
@@ -80,8 +99,8 @@ def host_cpu_share(nproc):
 def measured_traffic(workload, kernels):
     """HBM bytes per launch from the committed PMC passes (profiles/rNN_<workload>.json, written by
     tools/summarize_prof.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of THIS command,
-    FETCH_SIZE corrected by the calibrated gfx950 factor).  None when no profile of the current kernel
-    set is committed -- counters cannot be collected from inside an un-profiled run."""
+    FETCH_SIZE corrected by the calibrated gfx950 factor); the newest profile whose kernel set matches the
+    kernels of this run.  None otherwise -- counters cannot be collected from inside an un-profiled run."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}.json"))):
@@ -90,13 +109,19 @@ def measured_traffic(workload, kernels):
         except Exception:
             continue
         ks = [k for k in d.get("kernels", []) if "hbm_traffic_bytes" in k]
-        if ks and len(ks) == len(set(kernels)):
-            best = (sum(k["hbm_traffic_bytes"] for k in ks), os.path.basename(f))
+        names = " ".join(k["kernel"] for k in ks)
+        if ks and len(ks) == len(set(kernels)) and (d.get("bench_kernels") in (None, sorted(set(kernels)))):
+            best = (sum(k["hbm_traffic_bytes"] for k in ks), os.path.basename(f), names)
     return best
 
 
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N=1): the oracle port + the comparators of benchmark-cpu-others/benchmark.py:41-49
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(shape, bases, budget_s=12.0):
-    """Oracle timed on a bounded sample (leading-batch subset) of the workload."""
+    """Oracle timed on a bounded sample (leading-batch subset) of the workload: all host threads (the `value`),
+    one thread (the reference README's single-thread table, README.md:98-115), and beside them
+    scipy.fft.fftn(workers=-1) and numpy.fft.fftn on complex64 like the reference's competitor harness."""
     import numpy as np
     from oracle import mifft_oracle as O
 
@@ -104,26 +129,86 @@ def cpu_baseline(shape, bases, budget_s=12.0):
     rng = np.random.default_rng(1234)
     per = int(np.prod(shape[1:]))
 
-    def run(b):
+    def run(b, workers):
         x = rng.standard_normal((b,) + tuple(shape[1:]) + (2,), dtype=np.float32)
         out = np.empty_like(x)
         plan = O.plan_fft(np.float32, np.float32, x.shape, x.shape, bases=bases, default_target="gpu")
-        O.fft(out, x, plan=plan, cpu_workers=cores)  # warm-up (page faults, thread pool)
+        O.fft(out, x, plan=plan, cpu_workers=workers)  # warm-up (page faults, thread pool)
         t = time.perf_counter()
-        O.fft(out, x, plan=plan, cpu_workers=cores)
+        O.fft(out, x, plan=plan, cpu_workers=workers)
         return time.perf_counter() - t
 
+    def gflops(b, t):
+        return flops_5nlogn((b,) + tuple(shape[1:])) / t / 1e9
+
     b0 = max(1, min(shape[0], (1 << 21) // per))
-    t0 = max(run(b0), 1e-4)
-    b1 = int(max(b0, min(shape[0], b0 * (budget_s / 2) / t0, (1 << 28) // per)))
-    t1 = run(b1) if b1 > b0 else t0
-    gflops = flops_5nlogn((b1,) + tuple(shape[1:])) / t1 / 1e9
-    return {
-        "value": round(gflops, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
+    t0 = max(run(b0, cores), 1e-4)
+    b1 = int(max(b0, min(shape[0], b0 * (budget_s / 3) / t0, (1 << 28) // per)))
+    t1 = run(b1, cores) if b1 > b0 else t0
+    res = {
+        "value": round(gflops(b1, t1), 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
         "sample": f"{b1} of {shape[0]} leading-batch entries of the same shape, all {cores} host threads, "
                   f"oracle/libmifft_oracle.so (C++ restatement of the reference CPU path), {t1 * 1e3:.1f} ms",
         "ms_per_transform": round(t1 * 1e3 / b1, 6),
     }
+    # one thread (README.md:102-110): a sample sized to about a sixth of the budget
+    bs = int(max(1, min(b1, b1 * (budget_s / 6) / max(t1 * cores, 1e-4))))
+    ts = run(bs, 1)
+    res["port_1thread"] = {"value": round(gflops(bs, ts), 3), "unit": "GFLOP/s", "cores": 1,
+                           "sample": f"{bs} entries, {ts * 1e3:.1f} ms"}
+    # comparators (benchmark-cpu-others/benchmark.py:35,41-49): complex64, axes = all but the batch
+    try:
+        import scipy.fft
+        bc = int(max(1, min(b1, (1 << 25) // per)))
+        data = (rng.standard_normal((bc,) + tuple(shape[1:]), dtype=np.float32)
+                + 1j * rng.standard_normal((bc,) + tuple(shape[1:]), dtype=np.float32)).astype(np.complex64)
+        axes = tuple(range(1, len(shape)))
+        repeats = 2 if data.size > 2e7 else 5
+
+        def avg(fn):
+            fn()  # warm-up
+            t = time.perf_counter()
+            for _ in range(repeats):
+                fn()
+            return (time.perf_counter() - t) / repeats
+
+        tsp = avg(lambda: scipy.fft.fftn(data, axes=axes, workers=cores))
+        res["scipy_fftn"] = {"value": round(gflops(bc, tsp), 3), "unit": "GFLOP/s", "cores": cores,
+                             "sample": f"scipy.fft.fftn(workers={cores}) (pocketfft), complex64, {bc} entries, "
+                                       f"{repeats} repeats, {tsp * 1e3:.1f} ms"}
+        bn = int(max(1, bc // 4))
+        tnp = avg(lambda: np.fft.fftn(data[:bn], axes=axes))
+        res["numpy_fftn"] = {"value": round(gflops(bn, tnp), 3), "unit": "GFLOP/s", "cores": 1,
+                             "sample": f"numpy.fft.fftn, complex64 in (computes in complex128), {bn} entries, "
+                                       f"{repeats} repeats, {tnp * 1e3:.1f} ms"}
+    except Exception as e:  # a missing comparator must not cost the bench line
+        res["comparators_error"] = repr(e)
+    return res
+
+
+def vendor_compare(timeout_s=240):
+    """Bench-only comparator column: rocFFT on the five BASELINE shapes through
+    tools/vendor_fft_bench, a separate executable in its own process (the analogue of
+    cufft-benchmark-main/cufft_benchmark.cu).  libmifft never links or calls a vendor FFT."""
+    exe = os.path.join(ROOT, "tools", "vendor_fft_bench")
+    if not os.path.exists(exe):
+        return {"error": "tools/vendor_fft_bench not built (make -C tools)"}
+    shapes = ["x".join(str(d) for d in WORKLOADS[w][0]) for w in ["1d_500kx128", DEFAULT_WORKLOAD] + OTHER_BASELINE_CONFIGS[1:]]
+    try:
+        r = subprocess.run([exe, "--iters", "50"] + shapes, capture_output=True, text=True, timeout=timeout_s)
+    except Exception as e:
+        return {"error": repr(e)}
+    rows = []
+    for line in r.stdout.splitlines():
+        try:
+            rows.append(json.loads(line))
+        except Exception:
+            pass
+    out = {"library": "rocFFT (ROCm 7.2), own process, out of place C2C fp32, HIP events over 50 back-to-back execs",
+           "rows": rows}
+    if r.returncode:
+        out["error"] = (r.stderr or "")[-300:]
+    return out
 
 
 def _claim_stdout():
@@ -135,139 +220,307 @@ def _claim_stdout():
     return os.fdopen(saved, "w")
 
 
-def main():
-    json_out = _claim_stdout()
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the array of the other BASELINE configs (N=1)")
+    ap.add_argument("--no-strong-leg", action="store_true", help="skip the config-5 strong-scaling object")
+    ap.add_argument("--compare-vendor", dest="vendor", action="store_true", default=None,
+                    help="rocFFT comparator column (default: on at N=1 when tools/vendor_fft_bench exists)")
+    ap.add_argument("--no-compare-vendor", dest="vendor", action="store_false")
     ap.add_argument("--faithful", action="store_true", help="force the literal stage-per-pass kernel family")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="arithmetic type (BASELINE metric: f32)")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks share the visible GPU(s) and talk over gloo: exercises the N-rank launch, split and "
+                         "timing code on a 1-GPU box (RCCL refuses two ranks on one device); not a scaling measurement")
+    return ap.parse_args(argv)
 
-    import torch
 
-    import hackathon_fft_amd as mf
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no WORLD_SIZE -> N fresh rank processes
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args, json_out):
+    """Runs BEFORE anything touches the GPU in this process (no torch import, no HIP call): every rank is a new
+    child process started with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as torch.distributed.run would."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line:
+        json_out.write(line + "\n")
+        json_out.flush()
+    bad = [rc for rc in rcs if rc]
+    if bad or not line:
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        return bad[0] if bad else 1
+    return 0
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # MIFFT_BENCH_FORCE_DIST=1 runs the RCCL code path even with one rank (1-GPU rehearsal of the N>1 launch)
-    distributed = world > 1 or os.environ.get("MIFFT_BENCH_FORCE_DIST") == "1"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: libmifft has no CPU path")
-    torch.cuda.set_device(local_rank)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world
 
-    shape, bases, cfg_idx = WORKLOADS[args.workload]
-    dev = torch.device("cuda", local_rank)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    tdt = torch.float32 if args.dtype == "f32" else torch.float64
-    esz = 4 if args.dtype == "f32" else 8
-    x = torch.randn(tuple(shape) + (2,), generator=gen, device=dev, dtype=tdt)
-    out = torch.empty_like(x)
-    ctx = mf.DeviceContext(local_rank)
-    if distributed:
-        # weak scaling: the global problem is world x (per-GPU shape); every rank owns one resident slab
-        from hackathon_fft_amd.dist import ShardedFFT
-        gshape = (shape[0] * world,) + tuple(shape[1:]) + (2,)
-        sharded = ShardedFFT(tdt, tdt, gshape, gshape, bases=bases, device=local_rank)
-        assert sharded.slab_in_shape == tuple(x.shape)
-        plan, ctx = sharded._backend.plan, sharded._backend.ctx
-    else:
-        plan = mf.plan_fft(tdt, tdt, x.shape, x.shape, bases=bases, ctx=ctx, faithful_stages=args.faithful)
+class Bench:
+    """One rank's state: device, process group, timing helpers."""
 
-    def barrier():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def __init__(self, args):
+        import torch
 
-    # clock / cache ramp: a short --warmup (a few ms of work) leaves the first timed steps 10-20 % slow, so the device
-    # is kept busy for >= 50 ms before the W warmup steps (untimed, outside the K timed steps)
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.05:
-        for _ in range(10):
-            mf.fft(out, x, ctx, plan=plan)
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        mf.fft(out, x, ctx, plan=plan)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mf.fft(out, x, ctx, plan=plan)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        import hackathon_fft_amd as mf
+        self.torch, self.mf, self.args = torch, mf, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: start it as "
+                             f"`python bench.py --gpus N` (it spawns the ranks) or under torch.distributed.run with "
+                             f"--nproc-per-node equal to --gpus")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: libmifft has no CPU path")
+        ndev = torch.cuda.device_count()
+        self.rehearse = bool(args.rehearse_on_one_gpu)
+        self.dev_index = self.local_rank % ndev if self.rehearse else self.local_rank
+        if self.dev_index >= ndev:
+            raise SystemExit(f"bench.py: rank {self.rank} wants device {self.dev_index}, {ndev} visible")
+        torch.cuda.set_device(self.dev_index)
+        self.dev = torch.device("cuda", self.dev_index)
+        # MIFFT_BENCH_FORCE_DIST=1 runs the RCCL code path even with one rank (1-GPU rehearsal of the N>1 launch)
+        self.distributed = self.world > 1 or os.environ.get("MIFFT_BENCH_FORCE_DIST") == "1"
+        self.dist = None
+        self.ranks_seen = 1
+        if self.distributed:
+            import torch.distributed as dist
+            self.dist = dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if self.rehearse:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            one = torch.ones(1, device="cpu" if self.rehearse else self.dev)
+            dist.all_reduce(one)
+            self.ranks_seen = int(one.item())
+            if self.ranks_seen != self.world:
+                raise SystemExit(f"bench.py: all-reduce saw {self.ranks_seen} ranks, expected {self.world}")
+        self.tdt = torch.float32 if args.dtype == "f32" else torch.float64
+        self.esz = 4 if args.dtype == "f32" else 8
+        self.ctx = mf.DeviceContext(self.dev_index)
 
-    # kernel-level time: HIP events on the launch stream, inside the library
-    launch_ms = mf.time_fft(out, x, plan=plan, iters=max(10, min(args.steps, 200)), ctx=ctx)
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.distributed:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
-    if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        total_flops = flops_5nlogn(shape) * n_gpus
-        value = total_flops / (ms_per_step * 1e-3) / 1e9
+    def allmax(self, v):
+        if not self.distributed:
+            return v
+        t = self.torch.tensor([v], device="cpu" if self.rehearse else self.dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn, steps, warmup):
+        """ramp (>= RAMP_S of back-to-back calls, untimed) + `warmup` untimed calls + EXACTLY `steps` timed calls
+        between barrier + synchronize on both sides; returns (max-over-ranks seconds, ramp calls, ramp seconds)."""
+        torch = self.torch
+        n_ramp = 0
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < RAMP_S:
+            for _ in range(10):
+                fn()
+            n_ramp += 10
+            torch.cuda.synchronize()
+        ramp_s = time.perf_counter() - t_ramp
+        for _ in range(warmup):
+            fn()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        return self.allmax(time.perf_counter() - t0), n_ramp, ramp_s
+
+    def make_input(self, shape, seed_offset=0):
+        torch = self.torch
+        gen = torch.Generator(device=self.dev).manual_seed(1234 + self.rank + seed_offset)
+        x = torch.randn(tuple(shape) + (2,), generator=gen, device=self.dev, dtype=self.tdt)
+        return x, torch.empty_like(x)
+
+    def run_workload(self, name, steps, warmup, plan=None, x=None, out=None):
+        """time one workload on this rank's GPU (every rank its own copy of the shape)"""
+        mf = self.mf
+        shape, bases, cfg_idx = WORKLOADS[name]
+        if x is None:
+            x, out = self.make_input(shape)
+        if plan is None:
+            plan = mf.plan_fft(self.tdt, self.tdt, x.shape, x.shape, bases=bases, ctx=self.ctx,
+                               faithful_stages=self.args.faithful)
+        elapsed, n_ramp, ramp_s = self.timed(lambda: mf.fft(out, x, self.ctx, plan=plan), steps, warmup)
+        # kernel-level time: HIP events on the launch stream, inside the library
+        launch_ms = mf.time_fft(out, x, plan=plan, iters=max(10, min(steps, 200)), ctx=self.ctx)
+        ms_per_step = elapsed * 1e3 / steps
         elems = 1
         for d in shape:
             elems *= d
-        algo_bytes = 4.0 * esz * elems  # one complex read + one complex write per element, per exec on ONE gpu
+        algo_bytes = 4.0 * self.esz * elems  # one complex read + one complex write per element, per exec on ONE gpu
         achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
         kernels = [plan.kernel_name(d) for d in range(len(shape) - 1)]
-        traffic = measured_traffic(args.workload, kernels)
-        result = {
-            "metric": "C2C GFLOP/s (5Nlog2N) + ms/transform, 100k×1024 fp32 @1/2/4/8 MI355X",
-            "value": round(value, 2),
-            "unit": "GFLOP/s",
-            "n_gpus": n_gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
+        traffic = measured_traffic(name, kernels)
+        return {
+            "workload": name, "baseline_config_index": cfg_idx, "shape": list(shape) + [2],
             "ms_per_step": round(ms_per_step, 5),
-            "us_per_transform": round(ms_per_step * 1e3 / shape[0], 6),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {
-                "workload": args.workload,
-                "baseline_config_index": cfg_idx,
-                "shape_per_gpu": list(shape) + [2],
-                "bases": bases if bases is not None else "reference gpu default",
-                "stages": [plan.stages(d) for d in range(len(shape) - 1)],
-                "kernels": kernels,
-                "launches_per_step": plan.num_launches,
-                "parallelism": f"batch-sharded x{n_gpus}, no data-path collective",
-                "input": "complex64 N(0,1), seed 1234+rank, resident in HBM",
-            },
+            "gflops": round(flops_5nlogn(shape) / (ms_per_step * 1e-3) / 1e9, 2),
+            "bases": bases if bases is not None else "reference gpu default",
+            "stages": [plan.stages(d) for d in range(len(shape) - 1)],
+            "kernels": kernels, "launches_per_step": plan.num_launches,
+            "ramp": {"ms": round(ramp_s * 1e3, 1), "execs": n_ramp},
             "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic[0] if traffic else None,
-                "traffic_source": traffic[1] if traffic else None,
-                "kernel": "+".join(kernels),
-                "algorithmic_bytes_per_launch": algo_bytes,
+                "traffic_source": (traffic[1] + " (committed rocprofv3 --pmc passes of this command)") if traffic else None,
+                "kernel": "+".join(kernels), "algorithmic_bytes_per_launch": algo_bytes,
                 "launch_ms_hip_events": round(launch_ms, 5),
             },
         }
-        if n_gpus == 1 and not args.no_cpu_baseline and args.dtype == "f32":
+
+    # ---- strong scaling: ONE config-5 batch over all ranks (SURVEY.md 8e) ----------------------------
+    def strong_leg(self, steps, warmup):
+        torch, mf = self.torch, self.mf
+        from hackathon_fft_amd.dist import ShardedFFT, all_shard_bounds
+        shape, bases, _ = WORKLOADS[STRONG_WORKLOAD]
+        gshape = tuple(shape) + (2,)
+        sharded = ShardedFFT(self.tdt, self.tdt, gshape, gshape, bases=bases, device=self.dev_index)
+        counts = [c for _, c in all_shard_bounds(shape[0], self.world)]
+        gen = torch.Generator(device=self.dev).manual_seed(4321 + self.rank)
+        x_slab = torch.randn(sharded.slab_in_shape, generator=gen, device=self.dev, dtype=self.tdt)
+        out_slab = torch.empty_like(x_slab)
+        t_res, _, _ = self.timed(lambda: sharded.fft(out_slab, x_slab), steps, warmup)
+        # end to end from a root-held tensor: scatter (grouped P2P over RCCL / xGMI), transform, gather
+        x_full = out_full = None
+        if self.rank == 0:
+            x_full = torch.randn(gshape, generator=gen, device=self.dev, dtype=self.tdt)
+            out_full = torch.empty_like(x_full)
+        e2e_steps = max(3, min(steps, 20))
+        for _ in range(2):
+            sharded.fft_from_root(out_full, x_full, root=0, device=self.dev)
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(e2e_steps):
+            sharded.fft_from_root(out_full, x_full, root=0, device=self.dev)
+        self.barrier()
+        t_e2e = self.allmax(time.perf_counter() - t0)
+        ms_res, ms_e2e = t_res * 1e3 / steps, t_e2e * 1e3 / e2e_steps
+        flops = flops_5nlogn(shape)
+        return {
+            "workload": STRONG_WORKLOAD, "baseline_config_index": 4, "scaling": "strong", "n_gpus": self.world,
+            "volumes_per_rank": counts, "ideal_speedup_vs_1gpu": round(shape[0] / max(counts), 3),
+            "compute_shards_resident": {"ms_per_step": round(ms_res, 5), "gflops": round(flops / (ms_res * 1e-3) / 1e9, 2),
+                                        "steps": steps},
+            "end_to_end_from_root": {"ms_per_step": round(ms_e2e, 5), "gflops": round(flops / (ms_e2e * 1e-3) / 1e9, 2),
+                                     "steps": e2e_steps,
+                                     "transport": ("gloo, host-staged (rehearsal)" if self.rehearse else
+                                                   "RCCL grouped send/recv root<->peers" if self.world > 1 else
+                                                   "none (one rank owns the whole batch)")},
+            "kernels": [sharded._backend.plan.kernel_name(d) for d in range(len(shape) - 1)] if sharded.count else [],
+        }
+
+
+def worker(args, json_out):
+    b = Bench(args)
+    mf = b.mf
+    strong = args.scaling == "strong"
+    name = args.workload or (STRONG_WORKLOAD if strong else DEFAULT_WORKLOAD)
+    shape, bases, cfg_idx = WORKLOADS[name]
+    result = {"metric": METRIC}
+    if strong:
+        leg = b.strong_leg(args.steps, args.warmup)
+        r = leg["compute_shards_resident"]
+        result.update({
+            "value": r["gflops"], "unit": "GFLOP/s", "n_gpus": b.world, "ranks_seen": b.ranks_seen,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": STRONG_WORKLOAD, "baseline_config_index": 4,
+                       "parallelism": f"one 10 x 128^3 batch split {leg['volumes_per_rank']} over {b.world} ranks",
+                       "input": "complex64 N(0,1), resident in HBM"},
+            "strong_config5": leg,
+        })
+    else:
+        if b.distributed:
+            # weak scaling: the global problem is world x (per-GPU shape); every rank owns one resident slab
+            from hackathon_fft_amd.dist import ShardedFFT
+            gshape = (shape[0] * b.world,) + tuple(shape[1:]) + (2,)
+            sharded = ShardedFFT(b.tdt, b.tdt, gshape, gshape, bases=bases, device=b.dev_index)
+            x, out = b.make_input(shape)
+            assert sharded.slab_in_shape == tuple(x.shape)
+            main = b.run_workload(name, args.steps, args.warmup, plan=sharded._backend.plan, x=x, out=out)
+        else:
+            main = b.run_workload(name, args.steps, args.warmup)
+        n_gpus = b.world
+        value = flops_5nlogn(shape) * n_gpus / (main["ms_per_step"] * 1e-3) / 1e9
+        result.update({
+            "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": n_gpus, "ranks_seen": b.ranks_seen,
+            "steps": args.steps, "warmup": args.warmup, "ramp": main["ramp"],
+            "ms_per_step": main["ms_per_step"], "us_per_transform": round(main["ms_per_step"] * 1e3 / shape[0], 6),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {
+                "workload": name, "baseline_config_index": cfg_idx, "shape_per_gpu": list(shape) + [2],
+                "bases": main["bases"], "stages": main["stages"], "kernels": main["kernels"],
+                "launches_per_step": main["launches_per_step"],
+                "parallelism": f"batch-sharded x{n_gpus}, no data-path collective" + (" (rehearsal: ranks share GPUs)" if b.rehearse else ""),
+                "input": "complex64 N(0,1), seed 1234+rank, resident in HBM",
+            },
+            "roofline": main["roofline"],
+        })
+        del main
+        b.torch.cuda.empty_cache()
+        if not args.no_strong_leg and name == DEFAULT_WORKLOAD and args.dtype == "f32" and not args.faithful:
+            result["strong_config5"] = b.strong_leg(max(10, min(args.steps, 100)), max(2, min(args.warmup, 10)))
+        if b.world == 1 and not args.no_configs and name == DEFAULT_WORKLOAD and args.dtype == "f32" and not args.faithful:
+            cfgs = []
+            for w in OTHER_BASELINE_CONFIGS:
+                c = b.run_workload(w, args.steps, args.warmup)
+                c.pop("shape", None)
+                cfgs.append(c)
+                b.torch.cuda.empty_cache()
+            result["configs"] = sorted(cfgs, key=lambda c: c["baseline_config_index"])
+    if b.rank == 0:
+        if b.world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
             result["cpu_baseline"] = cpu_baseline(shape, bases)
+        want_vendor = args.vendor if args.vendor is not None else (
+            b.world == 1 and name == DEFAULT_WORKLOAD and not strong and args.dtype == "f32" and not args.faithful)
+        if want_vendor and b.world == 1:
+            b.torch.cuda.synchronize()
+            result["vendor_rocfft"] = vendor_compare()
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    if b.distributed:
+        b.dist.barrier()
+        b.dist.destroy_process_group()
+
+
+def main():
+    json_out = _claim_stdout()
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, json_out))  # nothing in this process has touched torch or the GPU
+    worker(args, json_out)
 
 
 if __name__ == "__main__":

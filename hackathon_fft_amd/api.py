@@ -159,6 +159,12 @@ class Plan:
     def out_bytes(self) -> int:
         return int(_lib.lib().mifft_plan_out_bytes(self._h))
 
+    @property
+    def scratch_bytes(self) -> int:
+        """device bytes of the plan-owned scratch tensor (0 unless a long strided dimension or a three-launch
+        four-step needs one; the reference's plan always owns one, fft/fft/_ndim_fft_gpu.mojo:185)"""
+        return int(_lib.lib().mifft_plan_scratch_bytes(self._h))
+
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
         if h:

@@ -20,6 +20,7 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
     tp.tlo = pass.d_aux;   // TSTORE configurations only
     tp.thi = pass.d_aux2;
     tp.tcol = pass.d_aux3;
+    tp.reverse = pass.reverse;
     if (C::COLS) {
         tp.inner = pass.inner;
         tp.tiles_per_outer = (pass.inner + C::TILE - 1) / C::TILE;
@@ -56,7 +57,8 @@ static int prepare_tile() {
 struct FastEntry {
     bool tstore;      // four-step first pass: transposed + twiddled store (needs pass.d_aux / d_aux2)
     bool in_real;     // the kernel promotes a real (C_in = 1) tensor in its pass-0 load
-    int stream_pref;  // 1: only for streaming-size problems (non-temporal twin), -1: any size
+    int stream_pref;  // 1: only for streaming-size problems (non-temporal twin), 2: only as the first pass of a
+                      // cache-resident N-D transform (non-temporal LOADS), -1: any size
     int out_dtype;
     int N;
     bool cols;
@@ -83,6 +85,8 @@ struct FastEntry {
 #define MIFFT_CFG_STREAM(NAME, ...) MIFFT_CFG_X(false, false, 3, 1, NAME "_nt", __VA_ARGS__)
 // ... with non-temporal stores only (tiles staged through a flat LDS copy re-read their lines)
 #define MIFFT_CFG_STREAM_ST(NAME, ...) MIFFT_CFG_X(false, false, 2, 1, NAME "_nts", __VA_ARGS__)
+// ... with non-temporal loads only: first pass of an N-D transform whose `out` fits the Infinity Cache
+#define MIFFT_CFG_NTL(NAME, ...) MIFFT_CFG_X(false, false, 1, 2, NAME "_ntl", __VA_ARGS__)
 // column tile with the transposed + twiddled store (first pass of the four-step); pass LAST_DIRECT = false
 #define MIFFT_CFG_TS(NAME, ...) MIFFT_CFG_X(true, false, 0, -1, NAME "_ts", __VA_ARGS__)
 

@@ -30,6 +30,8 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG("rows16384_16x16x8x8", float, MIFFT_F32, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, false),
     MIFFT_CFG_STREAM_ST("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
     MIFFT_CFG_CR("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+    MIFFT_CFG_NTL("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_NTL("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_CR("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_CR("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     // ---- strided dimensions, fp32 (in place, LDS column tiles) ----
@@ -80,6 +82,7 @@ static int launch_plane(const Plan& plan, const DimPass& pass, const void* in, v
     tp.tiles_per_outer = 1;
     tp.n_rows = 0;
     tp.n_tiles = count * pass.outer;  // planes
+    tp.reverse = pass.reverse;
     auto k = plane_kernel<CR, CC>;
     const long long grid = tile_grid<CR>(plan.num_cus, tp.n_tiles);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(CR::THREADS), CR::LDS_BYTES, stream, tp);
@@ -99,6 +102,7 @@ static int prepare_plane() {
 }
 
 struct PlaneEntry {
+    bool ntl;  // non-temporal loads of x: first pass of a cache-resident N-D transform
     int out_dtype;
     int N1, N2;
     const char* name;
@@ -117,18 +121,25 @@ using Plane64R = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, 
 using Plane64C = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, true, false, true, TW_LDS, 2, false>;
 using Plane128R = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true>;
 using Plane128C = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false>;
+using Plane64RN = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false, 0, false, false, 1>;
+using Plane128RN = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true, 0, false, false, 1>;
 
 static const PlaneEntry kPlaneTable[] = {
-    {MIFFT_F32, 64, 64, "plane64x64_8x8", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>, 512,
-     Plane64R::LDS_BYTES},
-    {MIFFT_F32, 128, 128, "plane128x128_16x8", launch_plane<Plane128R, Plane128C>, prepare_plane<Plane128R, Plane128C>,
-     1024, Plane128R::LDS_BYTES},
+    {true, MIFFT_F32, 64, 64, "plane64x64_8x8_ntl", launch_plane<Plane64RN, Plane64C>,
+     prepare_plane<Plane64RN, Plane64C>, 512, Plane64RN::LDS_BYTES},
+    {true, MIFFT_F32, 128, 128, "plane128x128_16x8_ntl", launch_plane<Plane128RN, Plane128C>,
+     prepare_plane<Plane128RN, Plane128C>, 1024, Plane128RN::LDS_BYTES},
+    {false, MIFFT_F32, 64, 64, "plane64x64_8x8", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>,
+     512, Plane64R::LDS_BYTES},
+    {false, MIFFT_F32, 128, 128, "plane128x128_16x8", launch_plane<Plane128R, Plane128C>,
+     prepare_plane<Plane128R, Plane128C>, 1024, Plane128R::LDS_BYTES},
 };
 
 bool select_fast_plane(const Plan& plan, DimPass& pass) {
     if (plan.in_dtype != plan.out_dtype || plan.in_components != 2) return false;
     for (const PlaneEntry& e : kPlaneTable) {
         if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
+        if (e.ntl && !(plan.cache_resident_nd && plan.ndim > 2)) continue;  // a 2-D plane is the only pass: nothing to keep
         pass.kernel_name = e.name;
         pass.launch = e.launch;
         pass.prepare = e.prepare;
@@ -167,6 +178,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols || e.tstore) return false;
         if (e.in_real != (pass.first && plan.in_components == 1)) return false;
         if (e.stream_pref == 1 && !streaming) return false;
+        if (e.stream_pref == 2 && !(plan.cache_resident_nd && pass.first)) return false;
         // (a strided dimension with fewer columns than one tile still runs here: the ragged tile clamps its loads and
         //  masks its stores; the literal-stage alternative is an order of magnitude slower)
         pass.kernel_name = e.name;

@@ -10,12 +10,42 @@
 // SURVEY.md 8(f) item 3.  W_N^m comes from a two-level table W_N^{m mod L} * W_N^{L*(m div L)}, L = 1024,
 // both factors rounded once from long double (k1*n2 < N, so no modular reduction is needed).
 #include <cmath>
+#include <cstdlib>
 
 #include "fast_table.h"
 
 namespace mifft {
 
 static constexpr int kL = 1024;
+
+// The plan scratch (one tensor of the output size).  MIFFT_TEST_FAIL_SCRATCH_ALLOC=1 makes this allocation fail the
+// way an exhausted device does, so that the roll-back of a half-built route can be tested on any GPU.
+static hipError_t alloc_scratch(Plan& plan) {
+    if (plan.d_scratch) return hipSuccess;
+    plan.scratch_bytes = (size_t)plan.batch * (size_t)plan.prod * plan.out_elem_bytes();
+    if (!plan.scratch_bytes) return hipSuccess;
+    if (const char* e = getenv("MIFFT_TEST_FAIL_SCRATCH_ALLOC")) {
+        if (e[0] == '1') {
+            plan.scratch_bytes = 0;
+            return hipErrorOutOfMemory;
+        }
+    }
+    hipError_t e = hipMalloc(&plan.d_scratch, plan.scratch_bytes);
+    if (e != hipSuccess) {
+        plan.d_scratch = nullptr;
+        plan.scratch_bytes = 0;
+        (void)hipGetLastError();
+    }
+    return e;
+}
+
+static void free_pass_tables(DimPass& q) {
+    if (q.d_twiddle) (void)hipFree(q.d_twiddle);
+    if (q.d_aux) (void)hipFree(q.d_aux);
+    if (q.d_aux2) (void)hipFree(q.d_aux2);
+    if (q.d_aux3) (void)hipFree(q.d_aux3);
+    q.d_twiddle = q.d_aux = q.d_aux2 = q.d_aux3 = nullptr;
+}
 
 struct TTParams {
     const void* src;
@@ -36,8 +66,12 @@ __global__ __launch_bounds__(256) void transpose_twiddle_kernel(const TTParams p
     const V* tlo = (const V*)p.tlo;
     const V* thi = (const V*)p.thi;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+    const long long c0 = (long long)blockIdx.x * 32;
+    const long long row_blocks = (p.n1 + 31) / 32;
+    // grid.y is capped at 65535 blocks: a workgroup walks the row blocks y, y + gridDim.y, ...
+    for (long long rb = blockIdx.y; rb < row_blocks; rb += gridDim.y)
     for (long long b = blockIdx.z; b < p.batch; b += gridDim.z) {
+        const long long r0 = rb * 32;
         const V* s = src + b * p.n1 * p.n2;
         V* d = dst + b * p.n1 * p.n2;
 #pragma unroll
@@ -78,7 +112,8 @@ static int launch_transpose_twiddle(const Plan& plan, const DimPass& pass, const
     tp.batch = count * pass.outer;  // matrices per exec
     tp.inverse = plan.inverse;
     tp.apply_tw = pass.d_aux != nullptr;
-    dim3 grid((unsigned)((pass.fs_n2 + 31) / 32), (unsigned)((pass.fs_n1 + 31) / 32),
+    const long long row_blocks = (pass.fs_n1 + 31) / 32;
+    dim3 grid((unsigned)((pass.fs_n2 + 31) / 32), (unsigned)(row_blocks < 65535 ? row_blocks : 65535),
               (unsigned)(tp.batch < 4096 ? tp.batch : 4096));
     if (plan.out_dtype == MIFFT_F32)
         hipLaunchKernelGGL(transpose_twiddle_kernel<float>, grid, dim3(256), 0, stream, tp);
@@ -217,12 +252,15 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
             if (e2 == hipSuccess)
                 e2 = plan.out_dtype == MIFFT_F32 ? upload_col_table<float>(N, ts.N, ts.tile, &ts.d_aux3)
                                                  : upload_col_table<double>(N, ts.N, ts.tile, &ts.d_aux3);
-            plan.passes.push_back(ts);
-            plan.passes.push_back(p3);
             if (e2 != hipSuccess) {
+                free_pass_tables(ts);
+                free_pass_tables(p3);
                 why_not = std::string("device allocation: ") + hipGetErrorString(e2);
+                plan.alloc_failed = true;
                 return false;
             }
+            plan.passes.push_back(ts);
+            plan.passes.push_back(p3);
             return true;
         }
     }
@@ -254,15 +292,18 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
     if (e == hipSuccess)
         e = plan.out_dtype == MIFFT_F32 ? upload_two_level<float>(N, &p2.d_aux, &p2.d_aux2)
                                         : upload_two_level<double>(N, &p2.d_aux, &p2.d_aux2);
-    plan.scratch_bytes = (size_t)plan.batch * (size_t)plan.prod * plan.out_elem_bytes();
-    if (e == hipSuccess && plan.scratch_bytes) e = hipMalloc(&plan.d_scratch, plan.scratch_bytes);
+    if (e == hipSuccess) e = alloc_scratch(plan);
+    if (e != hipSuccess) {
+        free_pass_tables(p1);
+        free_pass_tables(p2);
+        free_pass_tables(p3);
+        why_not = std::string("device allocation: ") + hipGetErrorString(e);
+        plan.alloc_failed = true;
+        return false;
+    }
     plan.passes.push_back(p1);
     plan.passes.push_back(p2);
     plan.passes.push_back(p3);
-    if (e != hipSuccess) {
-        why_not = std::string("device allocation: ") + hipGetErrorString(e);
-        return false;
-    }
     return true;
 }
 
@@ -310,18 +351,19 @@ bool build_transposed_dim(Plan& plan, int dim_index, const std::vector<uint32_t>
     t_out.src_buf = 2;
     t_out.dst_buf = 1;
     if (rows.prepare && rows.prepare() != MIFFT_OK) return false;
+    // every allocation first; the three passes join the plan only when all of them succeeded (a plan that kept them
+    // with a NULL scratch would write through a null pointer at the first exec)
     hipError_t e = upload_twiddle_table(plan.out_dtype, N, plan.inverse != 0, &rows.d_twiddle);
-    if (e == hipSuccess && !plan.d_scratch) {
-        plan.scratch_bytes = (size_t)plan.batch * (size_t)plan.prod * plan.out_elem_bytes();
-        if (plan.scratch_bytes) e = hipMalloc(&plan.d_scratch, plan.scratch_bytes);
+    if (e == hipSuccess) e = alloc_scratch(plan);
+    if (e != hipSuccess) {
+        free_pass_tables(rows);
+        why_not = std::string("device allocation: ") + hipGetErrorString(e);
+        plan.alloc_failed = true;
+        return false;
     }
     plan.passes.push_back(t_in);
     plan.passes.push_back(rows);
     plan.passes.push_back(t_out);
-    if (e != hipSuccess) {
-        why_not = std::string("device allocation: ") + hipGetErrorString(e);
-        return false;
-    }
     return true;
 }
 

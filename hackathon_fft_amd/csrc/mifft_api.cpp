@@ -221,6 +221,22 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
         }
     }
 
+    // ---- 32-bit lane offsets of the column tiles (tile_kernel.h, lane_off): a strided dimension must span fewer than
+    //      2^32 elements, N * stride < 2^32 (a single transform of more than 32 GB; checked before any device work) ----
+    {
+        double inner = 1.0;
+        for (int i = ndim - 1; i >= 0; --i) {
+            if (i < ndim - 1 && (double)dims[i] * inner + 64.0 >= 4294967296.0) {
+                delete h;
+                return set_error(MIFFT_ERR_TOO_LARGE,
+                                 "dimension " + std::to_string(i) + " (" + std::to_string(dims[i]) + " points at stride " +
+                                     std::to_string((long long)inner) + ") spans 2^32 elements or more: strided tiles "
+                                     "address their elements with 32-bit lane offsets");
+            }
+            inner *= (double)dims[i];
+        }
+    }
+
     // ---- device ----
     const int ndev = device_count_quiet();
     if (device < 0 || device >= ndev) {
@@ -237,6 +253,17 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) p.num_cus = prop.multiProcessorCount;
+
+    // ---- Infinity-Cache policy for N-D transforms (experiment switch MIFFT_ND_CACHE: bit 0 = non-temporal loads of x
+    //      in the first pass when `out` fits the cache, bit 1 = in-place passes alternate their walking direction) ----
+    int nd_mode = 0;
+    if (const char* ev = getenv("MIFFT_ND_CACHE")) nd_mode = atoi(ev);
+    {
+        double max_mb = 250.0;
+        if (const char* ev = getenv("MIFFT_ND_CACHE_MAX_MB")) max_mb = atof(ev);
+        const double out_bytes = (double)batch * (double)p.prod * (double)p.out_elem_bytes();
+        p.cache_resident_nd = ndim >= 2 && (nd_mode & 1) && out_bytes <= max_mb * 1e6;
+    }
 
     // ---- passes in execution order: last dimension first ----
     p.stage_radices = ordered;
@@ -285,6 +312,11 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                     std::string why4;
                     const size_t before = p.passes.size();
                     if (build_fourstep(p, i, why4) && p.passes.size() == before + 2) continue;
+                    if (p.alloc_failed) {
+                        free_plan_device(p);
+                        delete h;
+                        return set_error(MIFFT_ERR_HIP, "four-step: " + why4);
+                    }
                     // no two-pass split: drop whatever was appended and fall through to the single-kernel path
                     for (size_t k = before; k < p.passes.size(); ++k) {
                         DimPass& q = p.passes[k];
@@ -317,6 +349,11 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
             if (!ok && ps.inner != 1 && ps.N > 4096) {
                 std::string whyt;
                 if (build_transposed_dim(p, i, ordered[i], processed[i], whyt)) continue;
+                if (p.alloc_failed) {  // out of device memory is an error, not a reason to try a slower kernel
+                    free_plan_device(p);
+                    delete h;
+                    return set_error(MIFFT_ERR_HIP, "transposed route of dimension " + std::to_string(i) + ": " + whyt);
+                }
             }
         }
         if (!ok) {
@@ -327,8 +364,10 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                 // batched 1-D complex transform; the reference has no path at all here off NVIDIA clusters)
                 std::string why4;
                 if (i == ndim - 1 && build_fourstep(p, i, why4)) continue;
+                const bool oom = p.alloc_failed;
                 free_plan_device(p);
                 delete h;
+                if (oom) return set_error(MIFFT_ERR_HIP, "four-step: " + why4);
                 return set_error(MIFFT_ERR_TOO_LARGE, why + (why4.empty() ? "" : "; four-step: " + why4));
             }
         }
@@ -346,6 +385,13 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
             free_plan_device(p);
             delete h;
             return hip_error(e, "twiddle table upload");
+        }
+    }
+    if (nd_mode & 2) {
+        int k = 0;
+        for (DimPass& ps : p.passes) {
+            const bool in_place = (ps.src_buf < 0 && !ps.first) || (ps.src_buf == 1 && ps.dst_buf == 1);
+            if (in_place) ps.reverse = (k++ % 2) == 0;
         }
     }
     *out_plan = h;
@@ -421,6 +467,8 @@ size_t mifft_plan_in_bytes(const mifft_plan* plan) {
 size_t mifft_plan_out_bytes(const mifft_plan* plan) {
     return plan ? (size_t)plan->p.batch * plan->p.prod * plan->p.out_elem_bytes() : 0;
 }
+
+size_t mifft_plan_scratch_bytes(const mifft_plan* plan) { return plan && plan->p.d_scratch ? plan->p.scratch_bytes : 0; }
 
 int mifft_time_exec(const mifft_plan* plan, const void* x, void* out, void* stream, int iters, float* ms_out) {
     if (!plan || !ms_out) return set_error(MIFFT_ERR_NULL, "plan or ms_out is NULL");

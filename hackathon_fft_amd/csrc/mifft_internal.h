@@ -69,6 +69,7 @@ struct DimPass {
     bool plane_needs_tw1 = false;     // rectangular fused plane: d_aux holds the W_N1 table of the column side
     void* jit_fn = nullptr;           // runtime-compiled kernel (hipFunction_t) of kernels_jit.cpp passes
     void* d_aux3 = nullptr;           // TSTORE passes: [tile][N] table of W^(c*k1) for the columns of one tile
+    bool reverse = false;             // in-place pass that walks its tiles last-to-first (TileParams::reverse)
 };
 
 struct Plan {
@@ -87,6 +88,10 @@ struct Plan {
     void* d_scratch = nullptr;  // four-step only: one tensor of the output size (the reference's calc_buf,
                                 // fft/fft/_ndim_fft_gpu.mojo:185, exists for EVERY plan; here only for dims > 16384)
     size_t scratch_bytes = 0;
+    bool alloc_failed = false;  // a route builder ran out of device memory: plan creation reports MIFFT_ERR_HIP
+    // N-D transform whose `out` tensor fits the 256-MiB Infinity Cache: the first pass reads x with non-temporal loads
+    // (x does not displace the row results) and later in-place passes alternate their walking direction
+    bool cache_resident_nd = false;
     size_t in_elem_bytes() const;
     size_t out_elem_bytes() const;  // bytes of one complex output element
 };

@@ -99,7 +99,13 @@ struct TileParams {
     const void* tlo;
     const void* thi;
     const void* tcol;  // [TILE][N]: W_M^(c * k1), the twiddle of column c0 + c relative to column c0
+    // walk the tiles from the last to the first.  An in-place pass that follows a pass over the same tensor then
+    // starts with the lines written LAST, i.e. the ones most likely to be still in the 256-MiB Infinity Cache (LRU:
+    // walking forward again would evict exactly the lines it is about to need).
+    int reverse;
 };
+
+MIFFT_DEV long long tile_id(const TileParams& p, long long t) { return p.reverse ? p.n_tiles - 1 - t : t; }
 
 constexpr int ilog2_ce(int v) {
     int l = 0;
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
         if (t < t_end) {
             long long base;
             int nv;
-            tile_geom<C>(p, t, base, nv);
+            tile_geom<C>(p, tile_id(p, t), base, nv);
             load_pass0<C>(p, pre, base, nv, tid0);
         }
     }
@@ -656,7 +662,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
 #endif
         long long base;
         int nv;
-        tile_geom<C>(p, t, base, nv);
+        const long long tt = tile_id(p, t);
+        tile_geom<C>(p, tt, base, nv);
         V cur[C::PREFETCH ? C::IPT(0) : 1][C::R(0)];
         if constexpr (C::PREFETCH) {
 #pragma unroll
@@ -667,7 +674,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             if (tn < t_end) {  // issue the next tile's HBM reads before this tile's arithmetic
                 long long nbase;
                 int nnv;
-                tile_geom<C>(p, tn, nbase, nnv);
+                tile_geom<C>(p, tile_id(p, tn), nbase, nnv);
                 load_pass0<C>(p, pre, nbase, nnv, tid);
             }
         }
@@ -711,8 +718,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
         run_pass<C, 0>(p, lds, twr, cur, base, nv, tid);
         if constexpr (C::TSTORE) {
             // transposed + twiddled flat store: out[o][c0 + c][k1] = tile[k1][c] * W^{k1 * (c0 + c)}
-            const long long o = t / p.tiles_per_outer;
-            const long long c0 = (t - o * p.tiles_per_outer) * C::TILE;
+            const long long o = tt / p.tiles_per_outer;
+            const long long c0 = (tt - o * p.tiles_per_outer) * C::TILE;
             V* gout = (V*)p.out + o * (long long)C::N * p.inner + c0 * (long long)C::N;
             const V* tlo = (const V*)p.tlo;
             const V* thi = (const V*)p.thi;
@@ -870,7 +877,7 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
     V pre[CR::PREFETCH ? CR::IPT(0) : 1][CR::R(0)];
     long long t = blockIdx.x;
     if constexpr (CR::PREFETCH) {
-        if (t < p.n_tiles) load_pass0<CR>(p, pre, t * PLANE, CR::TILE, tid0);
+        if (t < p.n_tiles) load_pass0<CR>(p, pre, tile_id(p, t) * PLANE, CR::TILE, tid0);
     }
     const int tid_entry = tid0;
     for (; t < p.n_tiles; t += gridDim.x) {
@@ -878,7 +885,7 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
 #ifndef MIFFT_NO_OPAQUE_TID
         asm volatile("" : "+v"(tid));
 #endif
-        const long long base = t * PLANE;
+        const long long base = tile_id(p, t) * PLANE;
         V cur[CR::PREFETCH ? CR::IPT(0) : 1][CR::R(0)];
         if constexpr (CR::PREFETCH) {
 #pragma unroll
@@ -886,7 +893,7 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
 #pragma unroll
                 for (int j = 0; j < CR::R(0); ++j) cur[k][j] = pre[k][j];
             const long long tn = t + gridDim.x;
-            if (tn < p.n_tiles) load_pass0<CR>(p, pre, tn * PLANE, CR::TILE, tid);
+            if (tn < p.n_tiles) load_pass0<CR>(p, pre, tile_id(p, tn) * PLANE, CR::TILE, tid);
         }
         run_pass<CR, 0>(p, lds, twr, cur, base, CR::TILE, tid);  // rows: HBM -> ... -> LDS (natural order)
         V none[1][CC::R(0)];

@@ -90,38 +90,76 @@ class ShardedFFT:
             self._backend.run(out_slab, x_slab)
 
     # ---- root-held tensor: split, transform, collect -------------------------------------
-    def _p2p(self, ops):
+    def _p2p(self, transfers):
+        """``transfers``: list of ("send" | "recv", tensor, peer).  One grouped batch (ncclGroupStart/End under RCCL, so
+        the root's sends to all peers -- and a loopback pair -- progress concurrently).  A process group that cannot move
+        device memory (gloo) gets pinned host staging copies; the transform itself always runs on the GPU."""
+        if not transfers:
+            return
+        backend = dist.get_backend(self.group)
+        if backend == "gloo":
+            # gloo has no pair to itself: a loopback transfer is a local copy there (RCCL executes it as a real
+            # grouped send/recv, which is what the loopback mode exists for)
+            me = [tr for tr in transfers if tr[2] == self.rank]
+            sends, recvs = [t for k, t, _ in me if k == "send"], [t for k, t, _ in me if k == "recv"]
+            for src, dst in zip(sends, recvs):
+                dst.copy_(src)
+            transfers = [tr for tr in transfers if tr[2] != self.rank]
+        staged = []
+        ops = []
+        for kind, t, peer in transfers:
+            buf = t
+            if backend == "gloo" and t.is_cuda:
+                buf = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+                if kind == "send":
+                    buf.copy_(t)
+                else:
+                    staged.append((t, buf))
+            elif not t.is_contiguous():
+                raise ValueError("slabs of the leading dimension are contiguous by construction")
+            ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer, self.group))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        for t, buf in staged:
+            t.copy_(buf)
 
     def fft_from_root(self, out_full: Optional[torch.Tensor], x_full: Optional[torch.Tensor], *, root: int = 0,
-                      device=None) -> None:
-        """``x_full`` / ``out_full`` are read / written on ``root`` only (may be None elsewhere)."""
-        if self.world == 1:
+                      device=None, loopback: bool = False) -> None:
+        """``x_full`` / ``out_full`` are read / written on ``root`` only (may be None elsewhere).
+
+        ``loopback=True`` also moves the ROOT's own slab through the process group (a grouped send-to-self /
+        receive-from-self pair into staging slabs) instead of transforming it where it lies.  It exists so that the
+        collective code path can be executed and checked on a single GPU (world_size 1 over RCCL); it costs two
+        extra device copies and is never what a production call wants."""
+        if self.world == 1 and not loopback:
             self.fft(out_full, x_full)
             return
         is_root = self.rank == root
-        if is_root:
-            dev = x_full.device
-            x_slab = x_full[self.first:self.first + self.count]
-            out_slab = out_full[self.first:self.first + self.count]
-            ops = [dist.P2POp(dist.isend, x_full[f:f + c], r, self.group)
-                   for r, (f, c) in enumerate(self.bounds) if r != root and c > 0]
-        else:
-            dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
-                                                     if torch.cuda.is_available() else torch.device("cpu"))
+        if not is_root or loopback:
+            dev = x_full.device if is_root else (
+                device if device is not None else (torch.device("cuda", torch.cuda.current_device())
+                                                   if torch.cuda.is_available() else torch.device("cpu")))
             x_slab = torch.empty(self.slab_in_shape, dtype=self.in_dtype, device=dev)
             out_slab = torch.empty(self.slab_out_shape, dtype=self.out_dtype, device=dev)
-            ops = [dist.P2POp(dist.irecv, x_slab, root, self.group)] if self.count > 0 else []
-        self._p2p(ops)
+        else:
+            x_slab = x_full[self.first:self.first + self.count]
+            out_slab = out_full[self.first:self.first + self.count]
+        tr = []
+        if is_root:
+            tr += [("send", x_full[f:f + c], r) for r, (f, c) in enumerate(self.bounds)
+                   if c > 0 and (r != root or loopback)]
+        if self.count > 0 and (not is_root or loopback):
+            tr.append(("recv", x_slab, root))
+        self._p2p(tr)
         if self.count:
             self._backend.run(out_slab, x_slab)
             if out_slab.is_cuda:
                 torch.cuda.current_stream(out_slab.device).synchronize()
+        tr = []
+        if self.count > 0 and (not is_root or loopback):
+            tr.append(("send", out_slab, root))
         if is_root:
-            ops = [dist.P2POp(dist.irecv, out_full[f:f + c], r, self.group)
-                   for r, (f, c) in enumerate(self.bounds) if r != root and c > 0]
-        else:
-            ops = [dist.P2POp(dist.isend, out_slab, root, self.group)] if self.count > 0 else []
-        self._p2p(ops)
+            tr += [("recv", out_full[f:f + c], r) for r, (f, c) in enumerate(self.bounds)
+                   if c > 0 and (r != root or loopback)]
+        self._p2p(tr)

@@ -99,8 +99,20 @@ typedef struct mifft_plan mifft_plan;
  *                 Lists are normalised exactly like _build_ordered_bases
  *                 (fft/fft/_utils.mojo:162-183).
  *  flags          MIFFT_FLAG_*.
- * The plan owns its device twiddle tables; there is no full-size scratch buffer
- * (the reference allocates one, _ndim_fft_gpu.mojo:185; this design never needs it).
+ * The plan owns its device twiddle tables (a few KiB per dimension).  The reference's
+ * plan always owns a scratch tensor of the output size (_ndim_fft_gpu.mojo:185); here
+ * only two routes do -- query it with mifft_plan_scratch_bytes():
+ *   - a STRIDED dimension longer than 4096 points (transpose -> rows -> transpose), and
+ *   - a contiguous dimension beyond one LDS row (> 16384 points) whose factorisation
+ *     has no transposed-store kernel (the three-launch four-step).
+ * Every other plan (all BASELINE configs) works without scratch: the contiguous
+ * dimension goes x -> out, the others run in place on out.  Running out of device
+ * memory for the scratch is MIFFT_ERR_HIP, never a silent fallback.
+ * A strided dimension must span fewer than 2^32 elements (N * stride < 2^32, i.e. one
+ * transform below 32 GB): MIFFT_ERR_TOO_LARGE otherwise.
+ * mifft_plan_stages() reports the user's literal stages; the executed kernel fuses
+ * consecutive stages into 2-4 register-butterfly passes unless
+ * MIFFT_FLAG_FAITHFUL_STAGES is set (mifft_plan_kernel_name() shows the fused radices).
  * `runtime_twfs`, `max_cluster_size` have no MI355X meaning and do not exist here.
  */
 int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_dtype,
@@ -150,6 +162,9 @@ int mifft_plan_num_launches(const mifft_plan* plan);
 /* required sizes in bytes of x and out for the full batch */
 size_t mifft_plan_in_bytes(const mifft_plan* plan);
 size_t mifft_plan_out_bytes(const mifft_plan* plan);
+/* bytes of the plan-owned scratch tensor (0 for plans that need none, see mifft_plan_create);
+ * reference: _GPUPlan.calc_buf, fft/fft/_ndim_fft_gpu.mojo:176-185, which exists for every plan */
+size_t mifft_plan_scratch_bytes(const mifft_plan* plan);
 
 /* --- planner helpers, usable without a device (pure host logic) --- */
 

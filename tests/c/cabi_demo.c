@@ -26,8 +26,9 @@ static double check_1d_f32(void) {
     if (mifft_plan_create(&plan, 0, MIFFT_F32, MIFFT_F32, 1, dims, B, 2, 0, bases, lens, MIFFT_FLAG_NONE) < 0) return 1e9;
     uint32_t stages[64];
     int ns = mifft_plan_stages(plan, 0, stages, 64);
-    printf("1-D: kernel %s, %d user stages of radix %u, %d launch(es)\n", mifft_plan_kernel_name(plan, 0), ns, stages[0],
-           mifft_plan_num_launches(plan));
+    printf("1-D: kernel %s, %d user stages of radix %u, %d launch(es), %zu scratch bytes\n",
+           mifft_plan_kernel_name(plan, 0), ns, stages[0], mifft_plan_num_launches(plan), mifft_plan_scratch_bytes(plan));
+    if (mifft_plan_scratch_bytes(plan) != 0) { printf("a 1024-point plan must not own a scratch tensor\n"); return 1e9; }
     if (mifft_exec(plan, dx, dy, NULL) < 0) return 1e9;
     hipDeviceSynchronize();
     hipMemcpy(y, dy, sizeof y, hipMemcpyDeviceToHost);

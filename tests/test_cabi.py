@@ -60,11 +60,20 @@ def _create(device, dims, batch=4, in_dtype=0, out_dtype=0, comps=2, bases=None)
     (dict(dims=[8], bases=[[1, 8]]), -6),
     (dict(dims=[8], bases=[[]]), -7),
     (dict(dims=[2 * 101]), -5),
+    # 32-bit lane offsets of the strided tiles: a strided dimension must span fewer than 2^32 elements
+    (dict(dims=[64, 16384, 16384], batch=1), -9),
+    (dict(dims=[4096, 1 << 20], batch=1), -9),
 ])
 def test_plan_validation_happens_on_the_host(kwargs, status):
     rc, h = _create(0, **kwargs)
     assert rc == status and not h.value
     assert _lib.lib().mifft_last_error()
+
+
+def test_strided_span_just_below_the_32_bit_limit_is_not_rejected_by_the_guard():
+    # 15 x 2^28 - 64 elements: passes the span guard and then fails only for want of a device here (or succeeds there)
+    rc, h = _create(-1, [15, 16384, 16384], batch=1)
+    assert rc == -10 and not h.value   # device -1: refused AFTER the host-side checks
 
 
 def test_no_cpu_fallback():

@@ -55,7 +55,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shape, bases, q):
+def _worker(rank, world, port, shape, bases, q, loopback=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -73,7 +73,8 @@ def _worker(rank, world, port, shape, bases, q):
         dist.all_gather_object(gathered, out_slab.numpy())
         # --- root-held tensor: scatter, transform, gather ---
         out_full = torch.full(full, float("nan")) if rank == 0 else None
-        sh.fft_from_root(out_full, x_all if rank == 0 else None, root=0, device=torch.device("cpu"))
+        sh.fft_from_root(out_full, x_all if rank == 0 else None, root=0, device=torch.device("cpu"),
+                         loopback=loopback)
         if rank == 0:
             from oracle import mifft_oracle as O
             ref = O.fftn(x_all.numpy(), bases=bases)
@@ -85,17 +86,19 @@ def _worker(rank, world, port, shape, bases, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape,bases", [
-    (2, (10, 64), [[2]]),
-    (2, (5, 12, 10), None),
-    (3, (10, 93), [[31, 3]]),   # uneven 4,3,3
-    (3, (2, 16), None),         # a rank with an empty slab
+@pytest.mark.parametrize("world,shape,bases,loopback", [
+    (2, (10, 64), [[2]], False),
+    (2, (5, 12, 10), None, False),
+    (3, (10, 93), [[31, 3]], False),   # uneven 4,3,3
+    (3, (2, 16), None, False),         # a rank with an empty slab
+    (1, (3, 64), [[2]], True),         # one rank, its slab sent to itself through the process group
+    (2, (5, 12, 10), None, True),      # the root's own slab takes the P2P path too
 ])
-def test_sharded_equals_single_rank_bit_for_bit(world, shape, bases):
+def test_sharded_equals_single_rank_bit_for_bit(world, shape, bases, loopback):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, bases, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, bases, q, loopback)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -108,3 +111,26 @@ def test_sharded_equals_single_rank_bit_for_bit(world, shape, bases):
     assert resident_ok, "concatenated shard outputs must equal the single-rank output bit for bit"
     assert root_ok and not has_nan
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_bench_launcher_starts_one_process_per_rank():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must itself start two rank processes (before torch or HIP is
+    touched).  There is no GPU here, so each rank stops at the device check -- which is enough to see that two ranks
+    with WORLD_SIZE=2 were started and that the launcher reports their failure."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the -m gpu rehearsal test")
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a HIP device") == 2, r.stderr[-2000:]
+    assert "rank exit codes" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_rejects_a_world_size_that_differs_from_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -425,6 +425,40 @@ int main(int argc, char** argv) {
         VN("10x10x10 t4 256 lds w1 nt1", 1, float, 1000, 3, 10, 10, 10, 1, 4, 256, false, true, true, TW_LDS, 1, false),
         VN("10x10x10 t2 256 lds w2 nt3", 3, float, 1000, 3, 10, 10, 10, 1, 2, 256, false, true, true, TW_LDS, 2, false),
     };
+#elif GROUP == 17  // ---- config 4 second pass again: fewer, larger passes (one LDS round trip) ----
+    const long long batch = 100, outer = 1, inner = 480;
+    const int N = 640;
+    std::vector<Variant> vs = {
+        V("c640 10x8x8 t16 512 lds pf", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        V("c640 20x32 t16 512 lds", float, 640, 2, 20, 32, 1, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 20x32 t16 512 lds pf", float, 640, 2, 20, 32, 1, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        V("c640 32x20 t16 512 lds", float, 640, 2, 32, 20, 1, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        V("c640 32x20 t16 512 lds pf", float, 640, 2, 32, 20, 1, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        V("c640 20x32 t16 256 lds", float, 640, 2, 20, 32, 1, 1, 16, 256, true, true, true, TW_LDS, 1, false),
+        V("c640 32x20 t16 256 lds", float, 640, 2, 32, 20, 1, 1, 16, 256, true, true, true, TW_LDS, 1, false),
+        V("c640 20x32 t16 1024 lds", float, 640, 2, 20, 32, 1, 1, 16, 1024, true, true, true, TW_LDS, 1, false),
+        V("c640 10x8x8 t16 256 glb w2", float, 640, 3, 10, 8, 8, 1, 16, 256, true, true, true, TW_GLOBAL, 2, false),
+        V("c640 20x32 t16 256 glb w2", float, 640, 2, 20, 32, 1, 1, 16, 256, true, true, true, TW_GLOBAL, 2, false),
+        V("c640 20x32 t8 256 lds w2", float, 640, 2, 20, 32, 1, 1, 8, 256, true, true, true, TW_LDS, 2, false),
+    };
+#elif GROUP == 18  // ---- config 5 last pass: z axis of 10 x 128^3, columns of 128 with inner 16384 ----
+    const long long batch = 10, outer = 1, inner = 16384;
+    const int N = 128;
+    std::vector<Variant> vs = {
+        V("c128 8x4x4 t16 256 lds w4", float, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
+        V("c128 16x8 t16 128 lds w4", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_LDS, 4, false),
+        V("c128 8x16 t16 128 lds w4", float, 128, 2, 8, 16, 1, 1, 16, 128, true, true, true, TW_LDS, 4, false),
+        V("c128 16x8 t16 256 lds w4", float, 128, 2, 16, 8, 1, 1, 16, 256, true, true, true, TW_LDS, 4, false),
+        V("c128 16x8 t32 256 lds w4", float, 128, 2, 16, 8, 1, 1, 32, 256, true, true, true, TW_LDS, 4, false),
+        V("c128 16x8 t32 512 lds w4", float, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 4, false),
+        V("c128 8x4x4 t32 512 lds w4", float, 128, 3, 8, 4, 4, 1, 32, 512, true, true, true, TW_LDS, 4, false),
+        V("c128 16x8 t64 512 lds w2", float, 128, 2, 16, 8, 1, 1, 64, 512, true, true, true, TW_LDS, 2, false),
+        V("c128 16x8 t16 128 lds w4 pf", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_LDS, 4, true),
+        V("c128 16x8 t32 256 lds w4 pf", float, 128, 2, 16, 8, 1, 1, 32, 256, true, true, true, TW_LDS, 4, true),
+        V("c128 8x4x4 t16 256 lds w4 pf", float, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, true),
+        V("c128 32x4 t16 64 lds w4", float, 128, 2, 32, 4, 1, 1, 16, 64, true, true, true, TW_LDS, 4, false),
+        V("c128 16x8 t16 128 reg w4", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_REG, 4, false),
+    };
 #else
 #error "define GROUP"
 #endif
