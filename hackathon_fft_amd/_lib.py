@@ -19,6 +19,7 @@ EXPORTS = (
     "mifft_plan_kernel_name", "mifft_plan_num_launches", "mifft_plan_in_bytes", "mifft_plan_out_bytes",
     "mifft_ordered_bases", "mifft_estimate_bases", "mifft_last_error", "mifft_status_string",
     "mifft_version", "mifft_device_count", "mifft_time_exec", "mifft_jit_precompile", "mifft_plan_scratch_bytes",
+    "mifft_plan_device_status",
 )
 
 
@@ -65,6 +66,7 @@ def lib() -> ctypes.CDLL:
     L.mifft_plan_out_bytes.restype = c.c_size_t
     L.mifft_plan_scratch_bytes.argtypes = [vp]
     L.mifft_plan_scratch_bytes.restype = c.c_size_t
+    L.mifft_plan_device_status.argtypes = [vp, vp, c.POINTER(c.c_uint32)]
     L.mifft_ordered_bases.argtypes = [c.c_uint32, u32p, c.c_int, u32p, c.c_int]
     L.mifft_estimate_bases.argtypes = [c.c_uint32, c.c_int, u32p, c.c_int]
     L.mifft_last_error.restype = c.c_char_p

@@ -165,6 +165,15 @@ class Plan:
         four-step needs one; the reference's plan always owns one, fft/fft/_ndim_fft_gpu.mojo:185)"""
         return int(_lib.lib().mifft_plan_scratch_bytes(self._h))
 
+    def device_status(self, ctx: Optional["DeviceContext"] = None) -> int:
+        """Device-side error flags raised by execs of this plan (read and cleared; 0 = none).  Only the opt-in
+        L2-resident image kernel can raise one (bounded XCD-barrier spin expired: bit 0; surplus workgroup: bit 1);
+        synchronises the stream in that case only."""
+        flags = ctypes.c_uint32(0)
+        stream = (ctx.stream if ctx is not None else torch.cuda.current_stream(self.device)).cuda_stream
+        check(_lib.lib().mifft_plan_device_status(self._h, stream, ctypes.byref(flags)))
+        return int(flags.value)
+
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
         if h:

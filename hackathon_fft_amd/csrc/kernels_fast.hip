@@ -48,6 +48,9 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_TS("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, false, TW_LDS, 2, false),
     MIFFT_CFG_TS("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, false, TW_LDS, 4, false),
     MIFFT_CFG_TS("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, false, TW_LDS, 4, false),
+    // 32 columns = 256-byte runs: the z axis of 10 x 128^3 0.0597 -> 0.0537 ms (tools/tune GROUP 18); taken when the
+    // stride is a multiple of 32 columns, the 16-column tile below otherwise
+    MIFFT_CFG("cols128_16x8_w32", float, MIFFT_F32, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, true, TW_LDS, 2, false),
@@ -91,6 +94,44 @@ static int launch_plane(const Plan& plan, const DimPass& pass, const void* in, v
     return MIFFT_OK;
 }
 
+// wave-private variant (plane_kernel_wp): LDS pitch N2 + PAD
+template <class CR, class CC, int PAD>
+static int launch_plane_wp(const Plan& plan, const DimPass& pass, const void* in, void* out, int64_t count,
+                           hipStream_t stream) {
+    if (count == 0) return MIFFT_OK;
+    using G = WavePlane<CR, CC, PAD>;
+    TileParams tp{};
+    tp.in = in;
+    tp.out = out;
+    tp.tw = pass.d_twiddle;
+    tp.inverse = plan.inverse;
+    tp.scale = plan.inverse ? 1.0 / ((double)pass.N * (double)pass.N1) : 1.0;
+    tp.inner = CC::TILE;
+    tp.tiles_per_outer = 1;
+    tp.n_tiles = count * pass.outer;  // planes
+    tp.reverse = pass.reverse;
+    long long per_cu = (160 * 1024) / (long long)G::LDS_BYTES;
+    if (per_cu > 2048 / CR::THREADS) per_cu = 2048 / CR::THREADS;
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)plan.num_cus * per_cu;
+    if (grid > tp.n_tiles) grid = tp.n_tiles;
+    hipLaunchKernelGGL((plane_kernel_wp<CR, CC, PAD>), dim3((unsigned)grid), dim3(CR::THREADS), G::LDS_BYTES, stream, tp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_error(e, "plane_kernel_wp launch");
+    return MIFFT_OK;
+}
+
+template <class CR, class CC, int PAD>
+static int prepare_plane_wp() {
+    using G = WavePlane<CR, CC, PAD>;
+    if (G::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)plane_kernel_wp<CR, CC, PAD>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    return MIFFT_OK;
+}
+
 template <class CR, class CC>
 static int prepare_plane() {
     if (CR::LDS_BYTES > 64 * 1024) {
@@ -122,17 +163,18 @@ using Plane64C = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, true, false, true, T
 using Plane128R = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true>;
 using Plane128C = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false>;
 using Plane64RN = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false, 0, false, false, 1>;
-using Plane128RN = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true, 0, false, false, 1>;
+// (a non-temporal twin of the 128 x 128 plane measured SLOWER: 75.5 -> 80.5 us for 1280 planes; its next-plane
+//  register prefetch already keeps the loads far ahead)
 
 static const PlaneEntry kPlaneTable[] = {
     {true, MIFFT_F32, 64, 64, "plane64x64_8x8_ntl", launch_plane<Plane64RN, Plane64C>,
      prepare_plane<Plane64RN, Plane64C>, 512, Plane64RN::LDS_BYTES},
-    {true, MIFFT_F32, 128, 128, "plane128x128_16x8_ntl", launch_plane<Plane128RN, Plane128C>,
-     prepare_plane<Plane128RN, Plane128C>, 1024, Plane128RN::LDS_BYTES},
     {false, MIFFT_F32, 64, 64, "plane64x64_8x8", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>,
      512, Plane64R::LDS_BYTES},
-    {false, MIFFT_F32, 128, 128, "plane128x128_16x8", launch_plane<Plane128R, Plane128C>,
-     prepare_plane<Plane128R, Plane128C>, 1024, Plane128R::LDS_BYTES},
+    // wave-private exchanges (plane_kernel_wp): 2 workgroup barriers per plane instead of 12; 1280 planes 0.0812 ->
+    // 0.0744 ms (tools/tune GROUP 7).  For 64 x 64 planes (four workgroups per CU already overlap) it ties.
+    {false, MIFFT_F32, 128, 128, "plane128x128_16x8_wp", launch_plane_wp<Plane128R, Plane128C, 8>,
+     prepare_plane_wp<Plane128R, Plane128C, 8>, 1024, WavePlane<Plane128R, Plane128C, 8>::LDS_BYTES},
 };
 
 bool select_fast_plane(const Plan& plan, DimPass& pass) {
@@ -179,6 +221,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         if (e.in_real != (pass.first && plan.in_components == 1)) return false;
         if (e.stream_pref == 1 && !streaming) return false;
         if (e.stream_pref == 2 && !(plan.cache_resident_nd && pass.first)) return false;
+        if (cols && e.tile > 16 && pass.inner % e.tile != 0) return false;  // wide tiles: whole tiles only
         // (a strided dimension with fewer columns than one tile still runs here: the ragged tile clamps its loads and
         //  masks its stores; the literal-stage alternative is an order of magnitude slower)
         pass.kernel_name = e.name;

@@ -254,9 +254,12 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) p.num_cus = prop.multiProcessorCount;
 
-    // ---- Infinity-Cache policy for N-D transforms (experiment switch MIFFT_ND_CACHE: bit 0 = non-temporal loads of x
-    //      in the first pass when `out` fits the cache, bit 1 = in-place passes alternate their walking direction) ----
-    int nd_mode = 0;
+    // ---- Infinity-Cache policy for N-D transforms.  MIFFT_ND_CACHE overrides it: bit 0 = the first pass reads x with
+    //      non-temporal loads when `out` fits the 256-MiB cache, so that x does not displace the row results the next pass
+    //      reads (100 x 640 x 480: rows 96.2 -> 92.6 us, columns 102.9 -> 88.1 us); bit 1 = in-place passes walk their
+    //      tiles in alternating directions, starting with the lines written last (10 x 128^3: 0.131 -> 0.128 ms,
+    //      100 x 64^3 with both: 0.151 -> 0.139 ms).  Results are bit-identical in every mode. ----
+    int nd_mode = 3;
     if (const char* ev = getenv("MIFFT_ND_CACHE")) nd_mode = atoi(ev);
     {
         double max_mb = 250.0;
@@ -270,7 +273,10 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
     auto upload_twiddles = [&](DimPass& ps) -> hipError_t {
         hipError_t e = upload_twiddle_table(out_dtype, ps.N, inverse != 0, &ps.d_twiddle);
         if (e == hipSuccess && ps.plane_needs_tw1) e = upload_twiddle_table(out_dtype, ps.N1, inverse != 0, &ps.d_aux);
-        if (e == hipSuccess && ps.needs_counters) e = hipMalloc(&ps.d_aux2, 16 * sizeof(unsigned));
+        if (e == hipSuccess && ps.needs_counters) {  // 16 per-launch counters + the sticky error word
+            e = hipMalloc(&ps.d_aux2, 20 * sizeof(unsigned));
+            if (e == hipSuccess) e = hipMemset(ps.d_aux2, 0, 20 * sizeof(unsigned));
+        }
         return e;
     };
     for (int i = ndim - 1; i >= 0; --i) {
@@ -469,6 +475,23 @@ size_t mifft_plan_out_bytes(const mifft_plan* plan) {
 }
 
 size_t mifft_plan_scratch_bytes(const mifft_plan* plan) { return plan && plan->p.d_scratch ? plan->p.scratch_bytes : 0; }
+
+int mifft_plan_device_status(const mifft_plan* plan, void* stream, uint32_t* flags_out) {
+    if (!plan || !flags_out) return set_error(MIFFT_ERR_NULL, "plan or flags_out is NULL");
+    *flags_out = 0;
+    DeviceGuard guard(plan->p.device);
+    MIFFT_HIP_TRY(guard.err);
+    for (const DimPass& ps : plan->p.passes) {
+        if (!ps.needs_counters || !ps.d_aux2) continue;
+        hipStream_t s = (hipStream_t)stream;
+        unsigned v = 0;
+        MIFFT_HIP_TRY(hipMemcpyAsync(&v, (const unsigned*)ps.d_aux2 + 16, sizeof v, hipMemcpyDeviceToHost, s));
+        MIFFT_HIP_TRY(hipMemsetAsync((unsigned*)ps.d_aux2 + 16, 0, sizeof v, s));
+        MIFFT_HIP_TRY(hipStreamSynchronize(s));
+        *flags_out |= v;
+    }
+    return MIFFT_OK;
+}
 
 int mifft_time_exec(const mifft_plan* plan, const void* x, void* out, void* stream, int iters, float* ms_out) {
     if (!plan || !ms_out) return set_error(MIFFT_ERR_NULL, "plan or ms_out is NULL");

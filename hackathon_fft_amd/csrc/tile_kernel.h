@@ -118,7 +118,7 @@ enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
 
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
-          bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false, typename IT_ = T_>
+          bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false, typename IT_ = T_, bool WSUB_ = false>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -146,7 +146,23 @@ struct TileCfg {
     }
     static constexpr int NB(int i) { return N / R(i); }
     static constexpr int ITEMS(int i) { return NB(i) * TILE; }
-    static constexpr int IPT(int i) { return (ITEMS(i) + THREADS - 1) / THREADS; }
+    // WSUB (column tiles): after pass 0 (radix R0) the transform falls apart into R0 independent sub-problems -- the
+    // elements at positions = p (mod R0) -- and every later pass works inside them.  With WSUB a wave OWNS SPW of these
+    // sub-problems (all TILE columns) for the passes 1..NP-1, so the exchanges between those passes touch only LDS
+    // positions of its own sub-problems: one wave's LDS instructions execute in order and no workgroup barrier is
+    // needed.  Two workgroup barriers per tile remain (after the pass-0 scatter, after the last gather) instead of
+    // 2 (NP - 1); the waves drift apart and overlap each other's butterflies, LDS traffic and HBM stores.
+    static constexpr bool WSUB = WSUB_;
+    static constexpr int WAVES = THREADS_ / 64;
+    static constexpr int SPW = WSUB_ ? R0_ / (WAVES > 0 ? WAVES : 1) : 1;  // sub-problems per wave
+    static constexpr int WSLOTS = 64 / (TILE_ <= 64 ? TILE_ : 64);        // (sub-problem, butterfly) pairs per wave instruction
+    static constexpr int WPER(int i) { return SPW * (NB(i) / R0_); }      // ... per wave and pass
+    static_assert(!WSUB_ || (COLS_ && THREADS_ % 64 == 0 && 64 % TILE_ == 0 && R0_ % (THREADS_ / 64) == 0 && !TSTORE_ &&
+                             TWMODE_ != TW_REG && NP_ >= 2 && FIRST_DIRECT_ && LAST_DIRECT_ && R0_ <= 32),
+                  "WSUB: column tile, TILE divides a wave, R0 a multiple of the wave count");
+    static constexpr int IPT(int i) {
+        return (WSUB_ && i >= 1) ? (WPER(i) + WSLOTS - 1) / WSLOTS : (ITEMS(i) + THREADS - 1) / THREADS;
+    }
     static constexpr int TW_OFF(int i) {  // register twiddles of passes 1..i-1 precede pass i
         int o = 0;
         for (int k = 1; k < i; ++k) o += IPT(k) * (R(k) - 1);
@@ -277,6 +293,30 @@ MIFFT_DEV void item_decode(int id, int& c, int& b) {
     }
 }
 
+// work item k of thread tid in pass I -> (transform c of the tile, butterfly b); false: no such item
+template <class C, int I>
+MIFFT_DEV bool item_of(int tid, int k, int& c, int& b) {
+    if constexpr (C::WSUB && I >= 1) {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int m = k * C::WSLOTS + lane / C::TILE;  // pair (local sub-problem, butterfly inside it)
+        c = lane % C::TILE;
+        const int pl = m % C::SPW, qq = m / C::SPW;
+        b = qq * C::R(0) + wave * C::SPW + pl;  // b mod R0 = the sub-problem
+        return (C::WPER(I) % C::WSLOTS == 0) || m < C::WPER(I);
+    } else {
+        const int id = tid + k * C::THREADS;
+        item_decode<C, I>(id, c, b);
+        return (C::ITEMS(I) % C::THREADS == 0) || id < C::ITEMS(I);
+    }
+}
+
+// order one wave's LDS accesses across a pass boundary for the COMPILER (the hardware executes one wave's LDS
+// instructions in order; there is nothing to wait for)
+MIFFT_DEV void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <class C>
 MIFFT_DEV void tile_geom(const TileParams& p, long long t, long long& base, int& nv) {
     if constexpr (C::COLS) {
@@ -375,6 +415,10 @@ MIFFT_DEV void load_pass0(const TileParams& p, cpx<typename C::T> (*v)[C::R(0)],
 // drains vmcnt and with it the asynchronous copy (cdna_hip_programming.md, "Pipelining across barriers").
 template <class C>
 MIFFT_DEV void wg_barrier() {
+#ifdef MIFFT_ABLATE_BARRIERS  // timing experiment only (results are wrong): what do the workgroup barriers cost?
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return;
+#endif
     if constexpr (C::DMA)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else
@@ -388,13 +432,10 @@ MIFFT_DEV void pass_gather_lds(const TileParams& p, const cpx<typename C::T>* sr
     using T = typename C::T;
     using V = cpx<T>;
     constexpr int R = C::R(I), P = C::P(I), NB = C::NB(I), IPT = C::IPT(I), RATIO = C::N / (P * R);
-    constexpr bool EXACT = C::ITEMS(I) % C::THREADS == 0;
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-        const int id = tid + k * C::THREADS;
-        if (EXACT || id < C::ITEMS(I)) {
-            int c, b;
-            item_decode<C, I>(id, c, b);
+        int c, b;
+        if (item_of<C, I>(tid, k, c, b)) {
 #pragma unroll
             for (int j = 0; j < R; ++j) v[k][j] = src[lds_index<C, I - 1>(c, b + j * NB)];
             if constexpr (I > 0) {
@@ -429,15 +470,12 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
     using T = typename C::T;
     using V = cpx<T>;
     constexpr int R = C::R(I), P = C::P(I), IPT = C::IPT(I);
-    constexpr bool EXACT = C::ITEMS(I) % C::THREADS == 0;
     constexpr bool DST_GLOBAL = (I == C::NP - 1) && C::LAST_DIRECT;
     V* gout = (V*)p.out;
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-        const int id = tid + k * C::THREADS;
-        if (EXACT || id < C::ITEMS(I)) {
-            int c, b;
-            item_decode<C, I>(id, c, b);
+        int c, b;
+        if (item_of<C, I>(tid, k, c, b)) {
 #ifndef MIFFT_ABLATE_MATH  // timing experiment only: data movement without butterflies / twiddles
             Dft<R, T, 1>::run(v[k]);
 #endif
@@ -590,11 +628,21 @@ MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<
         } else {
             pass_gather_lds<C, I>(p, lds, lds + C::DATA_ELEMS + TWSHIFT, twr, v, tid);
             // in-place LDS buffer: every read of this pass completes before any later write (this
-            // pass's scatter, or pass 0 of the NEXT tile when this pass stores to HBM)
-            wg_barrier<C>();
+            // pass's scatter, or pass 0 of the NEXT tile when this pass stores to HBM).  WSUB: the passes 1..NP-2
+            // exchange inside wave-owned sub-problems -- only the LAST gather must hold back the other waves' next
+            // tile
+            if constexpr (C::WSUB && I >= 1 && I < C::NP - 1)
+                wave_lds_fence();
+            else
+                wg_barrier<C>();
         }
         pass_compute_scatter<C, I>(p, lds, v, base, nv, tid);
-        if constexpr (!DST_GLOBAL) wg_barrier<C>();
+        if constexpr (!DST_GLOBAL) {
+            if constexpr (C::WSUB && I >= 1 && I < C::NP - 1)
+                wave_lds_fence();
+            else
+                wg_barrier<C>();
+        }
         run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid);
     }
 }
@@ -902,6 +950,207 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
 }
 
 // ---------------------------------------------------------------------------------------------
+// plane_kernel_wp<CR, CC, PAD>: the fused plane with WAVE-PRIVATE exchanges.  plane_kernel above flattens the work items
+// of every pass over the whole workgroup, so each of its six LDS exchanges needs two workgroup barriers and all 16 waves
+// move through load / butterfly / LDS phases in lockstep (measured on 1280 planes of 128 x 128: VALU 24 % busy, LDS 22 %,
+// HBM 55 %; removing the barriers -- wrong results, timing only -- saves 11-15 %).  Here a wave OWNS whole transforms:
+//   row phase    wave w transforms rows [w*RPW, (w+1)*RPW) through all row passes; the exchanges between its passes touch
+//                only its own rows of the LDS plane, and LDS instructions of one wave execute in order, so no barrier
+//   hand-over    ONE workgroup barrier (rows complete -> columns may start)
+//   column phase wave w transforms columns [w*CPW, (w+1)*CPW) through all column passes, again without a barrier; the last
+//                pass stores to HBM (runs of CPW elements per row)
+//   a second barrier after the last LDS read of the plane protects the plane buffer against the next plane's first write.
+// Two barriers per plane instead of twelve, and the waves drift apart, so one wave's butterflies overlap another's LDS
+// and HBM traffic.  LDS pitch N2 + PAD (PAD = 8 elements: four consecutive rows of a CPW-column block fall into four
+// different 64-byte bank groups).  Row-phase exchanges keep the XOR swizzle of the rows configuration.
+// Requirements: the configurations of plane_kernel; N1 % WAVES == 0, N2 % WAVES == 0, CPW a power of two <= 64, every pass
+// an exact number of wave rounds.
+// ---------------------------------------------------------------------------------------------
+template <class CR, class CC, int PAD_>
+struct WavePlane {
+    static constexpr int N2 = CR::N, N1 = CC::N, THREADS = CR::THREADS, WAVES = THREADS / 64;
+    static constexpr int RPW = N1 / WAVES, CPW = N2 / WAVES, BPL = 64 / (CPW > 0 ? CPW : 1);
+    static constexpr int PITCH = N2 + PAD_;
+    static constexpr int DATA = N1 * PITCH;
+    static constexpr bool SHARED_TW = CR::N == CC::N && CR::NP == CC::NP && CR::R(0) == CC::R(0) && CR::R(1) == CC::R(1) &&
+                                      CR::R(2) == CC::R(2) && CR::R(3) == CC::R(3);
+    static constexpr int CSHIFT = SHARED_TW ? 0 : CR::TWL_TOTAL;
+    static constexpr size_t LDS_BYTES = (size_t)(DATA + CSHIFT + CC::TWL_TOTAL) * 2 * sizeof(typename CR::T);
+    static constexpr int RIPT(int i) { return RPW * CR::NB(i) / 64; }
+    static constexpr int CIPT(int i) { return CC::NB(i) / BPL; }
+    static constexpr bool exact() {
+        if (THREADS % 64 || N1 % WAVES || N2 % WAVES || CPW < 1 || CPW > 64 || (CPW & (CPW - 1))) return false;
+        for (int i = 0; i < CR::NP; ++i)
+            if ((RPW * CR::NB(i)) % 64) return false;
+        for (int i = 0; i < CC::NP; ++i)
+            if (CC::NB(i) % BPL) return false;
+        return true;
+    }
+};
+
+template <class CR, class CC, int PAD>
+MIFFT_DEV void wp_load_rows(const TileParams& p, cpx<typename CR::T> (*v)[CR::R(0)], long long base, int wave, int lane) {
+    using G = WavePlane<CR, CC, PAD>;
+    using V = cpx<typename CR::T>;
+    constexpr int R = CR::R(0), NB = CR::NB(0), IPT = G::RIPT(0);
+    const V* gin = (const V*)p.in;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int sub = k * 64 + lane, rl = sub / NB, b = sub - rl * NB;
+        const unsigned off = (unsigned)(wave * G::RPW + rl) * (unsigned)G::N2 + (unsigned)b;
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[k][j] = gload<(CR::NT & 1) != 0>(gin + base + j * NB + off);
+    }
+}
+
+template <class CR, class CC, int PAD, int I>
+MIFFT_DEV void wp_row_passes(const TileParams& p, cpx<typename CR::T>* lds, cpx<typename CR::T> (*pre)[CR::R(0)], int wave,
+                             int lane) {
+    if constexpr (I < CR::NP) {
+        using G = WavePlane<CR, CC, PAD>;
+        using T = typename CR::T;
+        using V = cpx<T>;
+        constexpr int R = CR::R(I), P = CR::P(I), NB = CR::NB(I), IPT = G::RIPT(I);
+        const V* ltw = lds + G::DATA;
+        V v[IPT][R];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int sub = k * 64 + lane, rl = sub / NB, b = sub - rl * NB;
+            V* row = lds + (wave * G::RPW + rl) * G::PITCH;
+            if constexpr (I == 0) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    v[k][j] = pre[k][j];
+                    if (p.inverse) v[k][j].y = -v[k][j].y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < R; ++j) v[k][j] = row[swz<CR, I - 1>(b + j * NB)];
+                const int pp = b % P;
+#pragma unroll
+                for (int j = 1; j < R; ++j) v[k][j] = cmul(v[k][j], ltw[CR::TWL_OFF(I) + (j - 1) * P + pp]);
+            }
+        }
+        if constexpr (I > 0) wave_lds_fence();  // this wave's reads of the exchange precede its writes below
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int sub = k * 64 + lane, rl = sub / NB, b = sub - rl * NB;
+            V* row = lds + (wave * G::RPW + rl) * G::PITCH;
+            Dft<R, T, 1>::run(v[k]);
+            const int q = b / P, pp = b - q * P, o0 = q * P * R + pp;
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                if constexpr (I == CR::NP - 1)
+                    row[o0 + s * P] = v[k][s];  // hand-over layout: natural order
+                else
+                    row[swz<CR, I>(o0 + s * P)] = v[k][s];
+            }
+        }
+        wave_lds_fence();
+        wp_row_passes<CR, CC, PAD, I + 1>(p, lds, pre, wave, lane);
+    }
+}
+
+template <class CR, class CC, int PAD, int I>
+MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long long base, int wave, int lane) {
+    if constexpr (I < CC::NP) {
+        using G = WavePlane<CR, CC, PAD>;
+        using T = typename CR::T;
+        using V = cpx<T>;
+        constexpr int R = CC::R(I), P = CC::P(I), NB = CC::NB(I), IPT = G::CIPT(I);
+        const V* ltw = lds + G::DATA + G::CSHIFT;
+        const int cl = lane % G::CPW, bl = lane / G::CPW;
+        V* col = lds + wave * G::CPW + cl;
+        V v[IPT][R];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int b = bl + k * G::BPL;
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[k][j] = col[(b + j * NB) * G::PITCH];
+            if constexpr (I > 0) {
+                const int pp = b % P;
+#pragma unroll
+                for (int j = 1; j < R; ++j) v[k][j] = cmul(v[k][j], ltw[CC::TWL_OFF(I) + (j - 1) * P + pp]);
+            }
+        }
+        if constexpr (I == CC::NP - 1)
+            __syncthreads();  // last LDS read of this plane: the next plane's row passes may overwrite the buffer
+        else
+            wave_lds_fence();
+        V* gout = (V*)p.out;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int b = bl + k * G::BPL;
+            Dft<R, T, 1>::run(v[k]);
+            const int q = b / P, pp = b - q * P, o0 = q * P * R + pp;
+            if constexpr (I == CC::NP - 1) {
+                const unsigned off = (unsigned)o0 * (unsigned)G::N2 + (unsigned)(wave * G::CPW + cl);
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    V y = v[k][s];
+                    if (p.inverse) {
+                        y.x *= (T)p.scale;
+                        y.y *= -(T)p.scale;
+                    }
+                    gstore<(CC::NT & 2) != 0>(gout + base + (long long)s * P * G::N2 + off, y);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < R; ++s) col[(o0 + s * P) * G::PITCH] = v[k][s];
+            }
+        }
+        if constexpr (I < CC::NP - 1) wave_lds_fence();
+        wp_col_passes<CR, CC, PAD, I + 1>(p, lds, base, wave, lane);
+    }
+}
+
+template <class CR, class CC, int PAD>
+__global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const TileParams p) {
+    using G = WavePlane<CR, CC, PAD>;
+    using T = typename CR::T;
+    using V = cpx<T>;
+    static_assert(!CR::COLS && CC::COLS && CR::N == CC::TILE && CR::TILE == CC::N, "plane geometry");
+    static_assert(CR::THREADS == CC::THREADS && CR::TWMODE == TW_LDS && CC::TWMODE == TW_LDS, "one thread count, LDS twiddles");
+    static_assert(G::exact(), "every pass must be an exact number of wave rounds over wave-owned rows / columns");
+    static_assert(same_t<typename CR::IT, T>::value && !CR::IN_REAL, "complex input of the plan's dtype");
+    static_assert(G::LDS_BYTES <= 160 * 1024, "plane + twiddle tables must fit LDS");
+#ifdef MIFFT_STATIC_LDS
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+#else
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
+    V* lds = (V*)smem;
+    const int tid0 = threadIdx.x;
+    fill_lds_tw<CR, 1>(lds + G::DATA, (const V*)p.tw, tid0, p.inverse);
+    if constexpr (!G::SHARED_TW) fill_lds_tw<CC, 1>(lds + G::DATA + G::CSHIFT, (const V*)p.tlo, tid0, p.inverse);
+    __syncthreads();
+
+    constexpr long long PLANE = (long long)G::N1 * G::N2;
+    V pre[G::RIPT(0)][CR::R(0)];
+    long long t = blockIdx.x;
+    if (t < p.n_tiles) wp_load_rows<CR, CC, PAD>(p, pre, tile_id(p, t) * PLANE, tid0 >> 6, tid0 & 63);
+    for (; t < p.n_tiles; t += gridDim.x) {
+        int tid = tid0;  // opaque per plane: offsets are re-derived instead of being hoisted and kept live (tile_kernel)
+#ifndef MIFFT_NO_OPAQUE_TID
+        asm volatile("" : "+v"(tid));
+#endif
+        const int wave = tid >> 6, lane = tid & 63;
+        const long long base = tile_id(p, t) * PLANE;
+        V cur[G::RIPT(0)][CR::R(0)];
+#pragma unroll
+        for (int k = 0; k < G::RIPT(0); ++k)
+#pragma unroll
+            for (int j = 0; j < CR::R(0); ++j) cur[k][j] = pre[k][j];
+        const long long tn = t + gridDim.x;
+        if (CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD>(p, pre, tile_id(p, tn) * PLANE, wave, lane);
+        wp_row_passes<CR, CC, PAD, 0>(p, lds, cur, wave, lane);
+        __syncthreads();  // hand-over: every row is complete before any column starts
+        wp_col_passes<CR, CC, PAD, 0>(p, lds, base, wave, lane);
+        if (!CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD>(p, pre, tile_id(p, tn) * PLANE, wave, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // image_kernel<CR, CC>: the two innermost dimensions (N1 x N2, N2 contiguous) of images that do NOT fit LDS but fit
 // one XCD's 4-MB L2 (100 x 640 x 480: 2.4 MB each).  Every XCD owns whole images: its workgroups transform the rows
 // of an image (x -> out, configuration CR), meet at an XCD-LOCAL barrier, and transform the columns in place
@@ -924,7 +1173,7 @@ struct ImageParams {
     const void* tw_rows;  // W_N2
     const void* tw_cols;  // W_N1
     long long n_images;
-    unsigned* counters;  // [0..7] tickets, [8..15] arrivals
+    unsigned* counters;  // [0..7] tickets, [8..15] arrivals (zeroed before every launch), [16] sticky error flags
     int wgs_per_xcd;
     int inverse;
 };
@@ -935,13 +1184,19 @@ MIFFT_DEV unsigned xcc_id() {
     return v & 0xf;
 }
 
-MIFFT_DEV void xcd_barrier(unsigned* arrive, unsigned target, int tid) {
+// error flags of the image kernel (ImageParams::counters[16]; read and cleared by mifft_plan_device_status)
+enum { IMAGE_ERR_SPIN_EXPIRED = 1u, IMAGE_ERR_SURPLUS_WORKGROUP = 2u };
+
+MIFFT_DEV void xcd_barrier(unsigned* arrive, unsigned target, int tid, unsigned* err) {
     __syncthreads();  // workgroup-scope release: every wave's global stores of the phase are complete in L2
     if (tid == 0) {
         __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 20))
             __builtin_amdgcn_s_sleep(8);
+        // the bounded spin gave up: this workgroup goes on WITHOUT its XCD's row results being complete, so the output
+        // of this exec is not to be trusted -- say so where the host can see it
+        if (spins >= (1u << 20)) __hip_atomic_fetch_or(err, (unsigned)IMAGE_ERR_SPIN_EXPIRED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's L1 lines; nothing is written back
@@ -972,7 +1227,11 @@ __global__ __launch_bounds__(CR::THREADS, 1) void image_kernel(const ImageParams
     __syncthreads();
     const long long slot = s_slot, W = q.wgs_per_xcd;
     unsigned* arrive = q.counters + 8 + xcc;
-    if (slot >= W) return;  // more workgroups on this XCD than planned: they take no part (the probe rules this out)
+    if (slot >= W) {  // more workgroups on this XCD than planned (the plan-time probe rules this out): another XCD is
+                      // short of workgroups and its barrier cannot complete -- flag the exec and take no part
+        if (tid0 == 0) __hip_atomic_fetch_or(q.counters + 16, (unsigned)IMAGE_ERR_SURPLUS_WORKGROUP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
 
     TileParams pr{}, pc{};
     pr.in = q.in;
@@ -1000,7 +1259,7 @@ __global__ __launch_bounds__(CR::THREADS, 1) void image_kernel(const ImageParams
             run_pass<CR, 0, TWS_R>(pr, lds, twr, none_r, ibase + tr * CR::TILE * N2, (int)(left < CR::TILE ? left : CR::TILE), tid);
             __syncthreads();
         }
-        xcd_barrier(arrive, (unsigned)((++phase) * W), tid0);
+        xcd_barrier(arrive, (unsigned)((++phase) * W), tid0, q.counters + 16);
         for (long long tc = slot; tc < TILES_C; tc += W) {  // columns, in place, from this XCD's L2
             int tid = tid0;
             asm volatile("" : "+v"(tid));

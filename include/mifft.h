@@ -166,6 +166,18 @@ size_t mifft_plan_out_bytes(const mifft_plan* plan);
  * reference: _GPUPlan.calc_buf, fft/fft/_ndim_fft_gpu.mojo:176-185, which exists for every plan */
 size_t mifft_plan_scratch_bytes(const mifft_plan* plan);
 
+/*
+ * mifft_plan_device_status -- device-side error flags of the execs enqueued so far with this plan on `stream`;
+ * reads and clears them.  Only the opt-in L2-resident image kernel (MIFFT_JIT_IMAGE=1) can raise one: its
+ * XCD-local barrier spins are bounded, and an exec whose spin expired (bit 0) or that was dispatched with a surplus
+ * workgroup on one XCD (bit 1) has produced output that must not be trusted.  Every other kernel family has no
+ * inter-workgroup dependency and reports 0 without touching the device.  SYNCHRONISES `stream` when the plan
+ * contains such a pass -- this is a check to run after a batch of execs, not part of the exec path.
+ * No reference counterpart (the reference's only device-wide synchronisation is the kernel boundary,
+ * fft/fft/_ndim_fft_gpu.mojo:634-642).
+ */
+int mifft_plan_device_status(const mifft_plan* plan, void* stream, uint32_t* flags_out);
+
 /* --- planner helpers, usable without a device (pure host logic) --- */
 
 /* _build_ordered_bases (fft/fft/_utils.mojo:162-183) + the product / base==1 checks of

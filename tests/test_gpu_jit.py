@@ -259,6 +259,7 @@ def test_l2_resident_image_kernel_opt_in(shape, monkeypatch):
     x = rng.standard_normal(shape + (2,)).astype(np.float32)
     out, plan = _run(x)
     assert plan.kernel_name(1).startswith("image") and plan.num_launches == 1, plan.kernel_name(1)
+    assert plan.device_status() == 0           # no bounded spin expired, no surplus workgroup (sticky device flags)
     truth = np.fft.fftn(to_complex(x), axes=(1, 2))
     assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
     again, _ = _run(x)

@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof_<tag>_<workload>/ (rocprofv3 CSVs) into profiles/<tag>_<workload>.json + .md.
 
-HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from
-separate passes, are in KiB, and FETCH_SIZE under-counts wide coalesced reads on gfx950 -- the
-correction factor is calibrated on a kernel of the same access pattern that moves a known byte count
-(tools/micro/copy_shapes.hip, `copy_row_f2`: 819.2 MB read + 819.2 MB written per launch)."""
+Kernel durations: from the kernel TRACE of `python3 bench.py --workload W --steps K --warmup W ...`, only the
+launches of the K TIMED steps are averaged -- bench.py prints how many execs its clock ramp ran, so the launches of
+ramp + warm-up (clocks and caches still settling; they raised the round-1 averages above the un-profiled
+ms_per_step) and of the trailing mifft_time_exec loop are dropped by position.  The un-profiled ms_per_step of the same
+command on the same box is stored beside them: sum of the timed-step kernel averages <= ms_per_step must hold.
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from separate
+passes, are in KiB, and FETCH_SIZE under-counts wide coalesced reads on gfx950 -- the correction factor is calibrated
+on a kernel of the same access pattern that moves a known byte count (tools/micro/copy_shapes.hip, `copy_row_f2`:
+819.2 MB read + 819.2 MB written per launch)."""
 import csv
 import glob
 import json
 import os
 import sys
-from collections import defaultdict
+from collections import OrderedDict, defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 wl = sys.argv[2] if len(sys.argv) > 2 else "1d_100kx1024_radix2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}_{wl}")
+HBM_PEAK = 8.0e12
+
+
+def is_ours(name):
+    return "mifft::" in name
 
 
 def short(name):
     name = name.replace("void ", "")
-    if "tile_kernel" in name or "generic_kernel" in name or "copy_" in name:
+    if is_ours(name) or "copy_" in name:
         return name[:160]
     return name[:60] + "..."
 
@@ -31,14 +42,33 @@ def newest(pattern):
     return [max(files, key=os.path.getmtime)] if files else []
 
 
-def kernel_stats(d):
+def bench_line(path):
+    try:
+        for ln in open(path):
+            if ln.startswith("{"):
+                return json.loads(ln)
+    except Exception:
+        pass
+    return None
+
+
+def timed_launches(d, line):
+    """durations (us) of our kernels during the K timed steps, keyed by kernel name in launch order"""
     rows = []
-    for f in newest(os.path.join(d, "**", "*kernel_stats.csv")):
+    for f in newest(os.path.join(d, "**", "*kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
-            rows.append({"kernel": short(r["Name"]), "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
-                         "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
-                         "pct": float(r["Percentage"])})
-    return sorted(rows, key=lambda r: -r["pct"])
+            if is_ours(r["Kernel_Name"]):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+    rows.sort()
+    L = line["config"]["launches_per_step"]
+    first = (line["ramp"]["execs"] + line["warmup"]) * L
+    last = first + line["steps"] * L
+    if len(rows) < last:
+        return None, len(rows)
+    per = OrderedDict()
+    for s, e, n in rows[first:last]:
+        per.setdefault(n, []).append((e - s) / 1e3)
+    return per, len(rows)
 
 
 def pmc(d, counter):
@@ -51,7 +81,11 @@ def pmc(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-stats = kernel_stats(os.path.join(src, "trace"))
+line = bench_line(os.path.join(src, "trace.log"))
+unprof = bench_line(os.path.join(src, "bench_unprofiled.json"))
+if line is None:
+    sys.exit(f"no bench JSON line in {src}/trace.log")
+per, n_all = timed_launches(os.path.join(src, "trace"), line)
 fetch = pmc(os.path.join(src, "pmc_FETCH_SIZE"), "FETCH_SIZE")
 write = pmc(os.path.join(src, "pmc_WRITE_SIZE"), "WRITE_SIZE")
 cal_fetch = pmc(os.path.join(src, "cal_FETCH_SIZE"), "FETCH_SIZE")
@@ -69,31 +103,57 @@ for k, v in cal_write.items():
         cal["write_factor"] = known / (v * 1024.0)
 
 kernels = []
-for s in stats:
-    if not ("tile_kernel" in s["kernel"] or "generic_kernel" in s["kernel"]):
-        continue
-    e = dict(s)
-    f = fetch.get(s["kernel"])
-    w = write.get(s["kernel"])
-    if f is not None and w is not None and cal.get("fetch_factor"):
-        e["FETCH_SIZE_KiB"] = f
-        e["WRITE_SIZE_KiB"] = w
-        e["hbm_read_bytes_corrected"] = f * 1024.0 * cal["fetch_factor"]
-        e["hbm_write_bytes_corrected"] = w * 1024.0 * cal["write_factor"]
-        e["hbm_traffic_bytes"] = e["hbm_read_bytes_corrected"] + e["hbm_write_bytes_corrected"]
-    kernels.append(e)
+if per:
+    for name, us in per.items():
+        e = {"kernel": name, "timed_launches": len(us), "launches_per_step": len(us) // line["steps"],
+             "avg_us": sum(us) / len(us), "min_us": min(us), "max_us": max(us)}
+        f, w = fetch.get(name), write.get(name)
+        if f is not None and w is not None and cal.get("fetch_factor"):
+            e["FETCH_SIZE_KiB"], e["WRITE_SIZE_KiB"] = f, w
+            e["hbm_read_bytes_corrected"] = f * 1024.0 * cal["fetch_factor"]
+            e["hbm_write_bytes_corrected"] = w * 1024.0 * cal["write_factor"]
+            e["hbm_traffic_bytes"] = e["hbm_read_bytes_corrected"] + e["hbm_write_bytes_corrected"]
+        kernels.append(e)
 
-res = {"tag": tag, "workload": wl, "calibration": cal, "kernels": kernels,
-       "other_kernels": [s for s in stats if not ("tile_kernel" in s["kernel"] or "generic_kernel" in s["kernel"])][:5]}
+algo = line["roofline"]["algorithmic_bytes_per_launch"]
+step_us = sum(k["avg_us"] * k["launches_per_step"] for k in kernels) if kernels else None
+res = {
+    "tag": tag, "workload": wl,
+    "command": f"python3 bench.py --workload {wl} --steps {line['steps']} --warmup {line['warmup']} --no-cpu-baseline "
+               "--no-configs --no-strong-leg --no-compare-vendor",
+    "bench_kernels": sorted(set(line["config"]["kernels"])),
+    "launches_in_trace": n_all, "ramp_execs": line["ramp"]["execs"], "warmup": line["warmup"], "steps": line["steps"],
+    "timed_step_kernel_us": step_us,
+    "roofline_frac_from_profile": (algo / (step_us * 1e-6) / HBM_PEAK) if step_us else None,
+    "profiled_run": {"ms_per_step": line["ms_per_step"], "launch_ms_hip_events": line["roofline"]["launch_ms_hip_events"],
+                     "frac": line["roofline"]["frac"]},
+    "unprofiled_run_same_box": ({"ms_per_step": unprof["ms_per_step"],
+                                 "launch_ms_hip_events": unprof["roofline"]["launch_ms_hip_events"],
+                                 "frac": unprof["roofline"]["frac"]} if unprof else None),
+    "calibration": cal, "kernels": kernels,
+}
+if step_us and unprof:
+    res["kernel_time_within_unprofiled_step"] = bool(step_us / 1e3 <= unprof["ms_per_step"] * 1.02)
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 base = os.path.join(root, "profiles", f"{tag}_{wl}")
 json.dump(res, open(base + ".json", "w"), indent=1)
 with open(base + ".md", "w") as f:
     f.write(f"# rocprofv3 summary {tag} / {wl}\n\n")
-    f.write("command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --steps 100 --warmup 20 --no-cpu-baseline`\n\n" % wl)
-    f.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
-    for s in stats[:6]:
-        f.write(f"| `{s['kernel'][:120]}` | {s['calls']} | {s['avg_us']:.2f} | {s['min_us']:.2f} | {s['max_us']:.2f} | {s['pct']:.2f} |\n")
+    f.write(f"command: `rocprofv3 --kernel-trace --stats -- {res['command']}`\n\n")
+    f.write(f"{n_all} launches of our kernels in the trace; the {line['steps']} timed steps are launches "
+            f"{(line['ramp']['execs'] + line['warmup']) * line['config']['launches_per_step']}.. "
+            f"(after {line['ramp']['execs']} ramp execs + {line['warmup']} warm-up steps).\n\n")
+    f.write("| kernel (timed steps only) | launches | avg us | min us | max us |\n|---|---|---|---|---|\n")
+    for k in kernels:
+        f.write(f"| `{k['kernel'][:120]}` | {k['timed_launches']} | {k['avg_us']:.2f} | {k['min_us']:.2f} | {k['max_us']:.2f} |\n")
+    if step_us:
+        f.write(f"\nkernel time per step {step_us:.2f} us -> {algo / 1e6:.1f} MB / {step_us:.2f} us / 8 TB/s = "
+                f"**{res['roofline_frac_from_profile']:.4f}**; profiled run's own line: ms_per_step {line['ms_per_step']}, "
+                f"HIP-event launch ms {line['roofline']['launch_ms_hip_events']} (frac {line['roofline']['frac']})")
+        if unprof:
+            f.write(f"; un-profiled run on the same box: ms_per_step {unprof['ms_per_step']}, HIP-event launch ms "
+                    f"{unprof['roofline']['launch_ms_hip_events']} (frac {unprof['roofline']['frac']})")
+        f.write(".\n")
     f.write("\nPMC (separate passes, per launch):\n\n")
     f.write(f"calibration on copy_row_f2 (known 819.2 MB each way): {json.dumps(cal)}\n\n")
     for k in kernels:

@@ -142,7 +142,41 @@ Variant make_plane(const char* name) {
     return v;
 }
 
+template <class CR, class CC, int PAD>
+Variant make_plane_wp(const char* name) {
+    Variant v;
+    v.name = name;
+    using G = WavePlane<CR, CC, PAD>;
+    v.lds = G::LDS_BYTES;
+    v.run = [](const void* in, void* out, const void* tw, long long batch, long long outer, long long inner) {
+        TileParams tp{};
+        tp.in = in;
+        tp.out = out;
+        tp.tw = tw;
+        tp.inverse = 0;
+        tp.scale = 1.0;
+        tp.inner = CC::TILE;
+        tp.tiles_per_outer = 1;
+        tp.n_tiles = batch * outer;  // planes
+        auto k = plane_kernel_wp<CR, CC, PAD>;
+        static bool set = false;
+        if (!set && G::LDS_BYTES > 64 * 1024) {
+            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+            set = true;
+        }
+        long long per_cu = (160 * 1024) / (long long)G::LDS_BYTES;
+        if (per_cu > 2048 / CR::THREADS) per_cu = 2048 / CR::THREADS;
+        if (per_cu < 1) per_cu = 1;
+        if (g_wg_override > 0) per_cu = g_wg_override;
+        long long grid = std::min<long long>(g_cus * per_cu, tp.n_tiles);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(CR::THREADS), G::LDS_BYTES, 0, tp);
+    };
+    return v;
+}
+
 #define V(NAME, ...) make<TileCfg<__VA_ARGS__>>(NAME)
+// wave-owned sub-problems after pass 0 (TileCfg::WSUB)
+#define VW(NAME, ...) make<TileCfg<__VA_ARGS__, 0, false, false, 0, false, float, true>>(NAME)
 // explicit non-temporal mode: ... PF, then NT (0 none, 1 loads, 2 stores, 3 both)
 #define VN(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, false, false, NT>>(NAME)
 // ... with an LDS row pad (ROWS: pitch = N + PAD)
@@ -155,6 +189,10 @@ Variant make_plane(const char* name) {
 #define PL(NAME, THR, MINW, PF, R0, R1, R2, R3, NP)                                                              \
     make_plane<TileCfg<float, 128, NP, R0, R1, R2, R3, 128, THR, false, true, false, TW_LDS, MINW, PF>,          \
                TileCfg<float, 128, NP, R0, R1, R2, R3, 128, THR, true, false, true, TW_LDS, MINW, false>>(NAME)
+
+#define PLW(NAME, PN, PAD, THR, MINW, PF, R0, R1, R2, R3, NP)                                                    \
+    make_plane_wp<TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, false, true, false, TW_LDS, MINW, PF>,         \
+                  TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, true, false, true, TW_LDS, MINW, false>, PAD>(NAME)
 
 #define PLN(NAME, PN, THR, MINW, PF, R0, R1, R2, R3, NP)                                                         \
     make_plane<TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, false, true, false, TW_LDS, MINW, PF>,            \
@@ -364,6 +402,15 @@ int main(int argc, char** argv) {
         PL("plane 16x8 1024 w4 pf", 1024, 4, true, 16, 8, 1, 1, 2),
         PL("plane 8x16 1024 w4", 1024, 4, false, 8, 16, 1, 1, 2),
         PL("plane 8x16 1024 w4 pf", 1024, 4, true, 8, 16, 1, 1, 2),
+        PLW("wp 16x8 1024 w4 pf pad8", 128, 8, 1024, 4, true, 16, 8, 1, 1, 2),
+        PLW("wp 16x8 1024 w4 pad8", 128, 8, 1024, 4, false, 16, 8, 1, 1, 2),
+        PLW("wp 16x8 1024 w4 pf pad0", 128, 0, 1024, 4, true, 16, 8, 1, 1, 2),
+        PLW("wp 8x16 1024 w4 pf pad8", 128, 8, 1024, 4, true, 8, 16, 1, 1, 2),
+        PLW("wp 8x4x4 1024 w4 pf pad8", 128, 8, 1024, 4, true, 8, 4, 4, 1, 3),
+        PLW("wp 4x4x8 1024 w4 pf pad8", 128, 8, 1024, 4, true, 4, 4, 8, 1, 3),
+        PLW("wp 16x8 512 w2 pf pad8", 128, 8, 512, 2, true, 16, 8, 1, 1, 2),
+        PLW("wp 16x8 512 w2 pf pad16", 128, 16, 512, 2, true, 16, 8, 1, 1, 2),
+        PLW("wp 8x16 512 w2 pf pad8", 128, 8, 512, 2, true, 8, 16, 1, 1, 2),
     };
 #elif GROUP == 13  // ---- 100 x 64^3: fused y+x planes, 6400 planes of 64x64 ----
     const long long batch = 100, outer = 64, inner = 1;
@@ -381,6 +428,11 @@ int main(int argc, char** argv) {
         PLN("plane64 16x4 256 w2", 64, 256, 2, false, 16, 4, 1, 1, 2),
         PLN("plane64 4x16 256 w2", 64, 256, 2, false, 4, 16, 1, 1, 2),
         PLN("plane64 8x8 1024 w4", 64, 1024, 4, false, 8, 8, 1, 1, 2),
+        PLW("wp64 8x8 512 w2 pad8", 64, 8, 512, 2, false, 8, 8, 1, 1, 2),
+        PLW("wp64 8x8 512 w2 pf pad8", 64, 8, 512, 2, true, 8, 8, 1, 1, 2),
+        PLW("wp64 8x8 256 w2 pf pad16", 64, 16, 256, 2, true, 8, 8, 1, 1, 2),
+        PLW("wp64 8x8 256 w4 pad16", 64, 16, 256, 4, false, 8, 8, 1, 1, 2),
+        PLW("wp64 4x4x4 512 w2 pf pad8", 64, 8, 512, 2, true, 4, 4, 4, 1, 3),
     };
 #elif GROUP == 14  // ---- long rows: 3906 x 8192 ----
     const long long batch = 3906, outer = 1, inner = 1;
@@ -458,6 +510,55 @@ int main(int argc, char** argv) {
         V("c128 8x4x4 t16 256 lds w4 pf", float, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, true),
         V("c128 32x4 t16 64 lds w4", float, 128, 2, 32, 4, 1, 1, 16, 64, true, true, true, TW_LDS, 4, false),
         V("c128 16x8 t16 128 reg w4", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_REG, 4, false),
+    };
+#elif GROUP == 19  // ---- config 3 again: radix 3 first (248-byte runs in pass 0), radix 31 last ----
+    const long long batch = 500000, outer = 1, inner = 1;
+    const int N = 93;
+    std::vector<Variant> vs = {
+        VN("31x3 t64 192 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+        VN("3x31 t64 192 w3 nt2 fd", 2, float, 93, 2, 3, 31, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+        VN("3x31 t64 192 w3 nt3 fd", 3, float, 93, 2, 3, 31, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+        VN("3x31 t64 192 w2 nt2 fd", 2, float, 93, 2, 3, 31, 1, 1, 64, 192, false, true, false, TW_LDS, 2, false),
+        VN("3x31 t64 192 w3 nt2 fd ld", 2, float, 93, 2, 3, 31, 1, 1, 64, 192, false, true, true, TW_LDS, 3, false),
+        VN("3x31 t64 192 w3 nt2 stg", 2, float, 93, 2, 3, 31, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
+        VN("3x31 t32 96 w3 nt2 fd", 2, float, 93, 2, 3, 31, 1, 1, 32, 96, false, true, false, TW_LDS, 3, false),
+        VN("3x31 t128 384 w3 nt2 fd", 2, float, 93, 2, 3, 31, 1, 1, 128, 384, false, true, false, TW_LDS, 3, false),
+        VN("3x31 t64 256 w3 nt2 fd", 2, float, 93, 2, 3, 31, 1, 1, 64, 256, false, true, false, TW_LDS, 3, false),
+        VN("3x31 t64 192 w3 nt2 fd pf", 2, float, 93, 2, 3, 31, 1, 1, 64, 192, false, true, false, TW_LDS, 3, true),
+        VN("3x31 t64 192 w3 nt2 fd reg", 2, float, 93, 2, 3, 31, 1, 1, 64, 192, false, true, false, TW_REG, 3, false),
+        VN("3x31 t48 192 w3 nt2 fd", 2, float, 93, 2, 3, 31, 1, 1, 48, 192, false, true, false, TW_LDS, 3, false),
+    };
+#elif GROUP == 20  // ---- config 4 second pass: wave-owned sub-problems (WSUB) ----
+    const long long batch = 100, outer = 1, inner = 480;
+    const int N = 640;
+    std::vector<Variant> vs = {
+        V("c640 10x8x8 t16 512 lds pf", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        V("c640 10x8x8 t16 640 lds pf", float, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_LDS, 1, true),
+        VW("c640 10x8x8 t16 640 wsub pf", float, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_LDS, 1, true),
+        VW("c640 10x8x8 t16 640 wsub", float, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_LDS, 1, false),
+        VW("c640 10x8x8 t16 320 wsub pf", float, 640, 3, 10, 8, 8, 1, 16, 320, true, true, true, TW_LDS, 1, true),
+        VW("c640 8x8x10 t16 512 wsub pf", float, 640, 3, 8, 8, 10, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        VW("c640 8x8x10 t16 512 wsub", float, 640, 3, 8, 8, 10, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        VW("c640 8x10x8 t16 512 wsub pf", float, 640, 3, 8, 10, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        VW("c640 16x8x5 t16 1024 wsub", float, 640, 3, 16, 8, 5, 1, 16, 1024, true, true, true, TW_LDS, 1, false),
+        VW("c640 16x8x5 t16 512 wsub pf", float, 640, 3, 16, 8, 5, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        VW("c640 16x5x8 t16 512 wsub pf", float, 640, 3, 16, 5, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        VW("c640 8x4x4x5 t16 512 wsub pf", float, 640, 4, 8, 4, 4, 5, 16, 512, true, true, true, TW_LDS, 1, true),
+        VW("c640 8x5x4x4 t16 512 wsub pf", float, 640, 4, 8, 5, 4, 4, 16, 512, true, true, true, TW_LDS, 1, true),
+        VW("c640 10x4x4x4 t16 640 wsub pf", float, 640, 4, 10, 4, 4, 4, 16, 640, true, true, true, TW_LDS, 1, true),
+    };
+#elif GROUP == 21  // ---- four-step passes / long strided dims: columns of 1024 with WSUB ----
+    const long long batch = 64, outer = 1, inner = 1024;
+    const int N = 1024;
+    std::vector<Variant> vs = {
+        V("c1024 16x8x8 t16 512 lds", float, 1024, 3, 16, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        VW("c1024 16x8x8 t16 1024 wsub", float, 1024, 3, 16, 8, 8, 1, 16, 1024, true, true, true, TW_LDS, 1, false),
+        VW("c1024 16x8x8 t16 512 wsub", float, 1024, 3, 16, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        VW("c1024 8x16x8 t16 512 wsub", float, 1024, 3, 8, 16, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        VW("c1024 8x8x16 t16 512 wsub", float, 1024, 3, 8, 8, 16, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        VW("c1024 16x4x4x4 t16 1024 wsub", float, 1024, 4, 16, 4, 4, 4, 16, 1024, true, true, true, TW_LDS, 1, false),
+        VW("c1024 8x8x4x4 t16 512 wsub", float, 1024, 4, 8, 8, 4, 4, 16, 512, true, true, true, TW_LDS, 1, false),
+        VW("c1024 8x4x4x8 t16 512 wsub", float, 1024, 4, 8, 4, 4, 8, 16, 512, true, true, true, TW_LDS, 1, false),
     };
 #else
 #error "define GROUP"
