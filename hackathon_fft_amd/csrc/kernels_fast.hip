@@ -52,6 +52,8 @@ static const FastEntry kFastTable[] = {
     // stride is a multiple of 32 columns, the 16-column tile below otherwise
     MIFFT_CFG("cols128_16x8_w32", float, MIFFT_F32, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
+    MIFFT_CFG("cols64_8x8_w64", float, MIFFT_F32, 64, 2, 8, 8, 1, 1, 64, 512, true, true, true, TW_LDS, 2, false),
+    MIFFT_CFG("cols64_8x8_w32", float, MIFFT_F32, 64, 2, 8, 8, 1, 1, 32, 256, true, true, true, TW_LDS, 2, false),
     MIFFT_CFG("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, true, TW_LDS, 2, false),
     // ---- fp64 (the reference's own tests run in float64, fft/tests.mojo:394-417): same template, 16-byte

@@ -309,6 +309,92 @@ bool build_fourstep(Plan& plan, int dim_index, std::string& why_not) {
 
 
 // ---------------------------------------------------------------------------------------------
+// Four-step for a STRIDED dimension too long for one column tile (N > 4096: the columns of 8K frames, ...).
+// N = N1 * N2; the dimension is viewed as [N1][N2] rows of `inner` contiguous elements:
+//   pass A  column tiles of N1 points (row stride N2 * inner), out -> scratch, row k1 of the tile (n2, columns) stored
+//           as row n2 * N1 + k1 and multiplied by W_N^(k1 n2)             (TileCfg::FS1, runtime-specialised)
+//   pass B  column tiles of N2 points (row stride N1 * inner), scratch -> out: row k2 * N1 + k1 = X[k1 + N1 k2]
+// Two passes with TILE-element runs on both sides instead of the three of the transposed route below (transpose, row
+// kernel, transpose) -- SURVEY.md 8(f).3; the reference has no path at all for such dimensions off NVIDIA clusters
+// (fft/fft/_ndim_fft_gpu.mojo:100-108, 510-519).
+// ---------------------------------------------------------------------------------------------
+bool build_fourstep_strided(Plan& plan, int dim_index, std::string& why_not) {
+    const int64_t N = plan.dims[dim_index];
+    int64_t inner = 1, outer = 1;
+    for (int k = dim_index + 1; k < plan.ndim; ++k) inner *= plan.dims[k];
+    for (int k = 0; k < dim_index; ++k) outer *= plan.dims[k];
+    if (inner == 1) {
+        why_not = "contiguous dimension";
+        return false;
+    }
+    if (const char* e = getenv("MIFFT_FOURSTEP_STRIDED"))
+        if (e[0] == '0') {
+            why_not = "MIFFT_FOURSTEP_STRIDED=0";
+            return false;
+        }
+    // most balanced factorisation whose factors both have a fused column configuration
+    int64_t best1 = 0, best2 = 0;
+    double best_score = 1e300;
+    for (int64_t n1 = 2; n1 <= 4096 && n1 < N; ++n1) {
+        if (N % n1) continue;
+        const int64_t n2 = N / n1;
+        if (n2 > 4096 || n2 < 2) continue;
+        if (!jit_cols_feasible(plan, n1, n2 * inner)) continue;
+        DimPass b;
+        std::string w;
+        Plan probe = plan;
+        probe.passes.clear();
+        const bool fb = (make_cols_pass(probe, dim_index, n2, n1 * inner, b, w) && std::string(b.kernel_name) != "generic") ||
+                        jit_cols_feasible(plan, n2, n1 * inner);
+        if (!fb) continue;
+        const double score = std::fabs(std::log((double)n1 / (double)n2));
+        if (score < best_score) {
+            best_score = score;
+            best1 = n1;
+            best2 = n2;
+        }
+    }
+    if (!best1) {
+        why_not = "no factorisation N1 * N2 with fused column tiles for both factors";
+        return false;
+    }
+    DimPass pa, pb;
+    pa.dim_index = dim_index;
+    pa.N = best1;
+    pa.inner = inner;
+    pa.outer = outer;
+    pa.fs_n1 = best1;
+    pa.fs_n2 = best2;
+    pa.first = false;
+    if (!select_jit_fs1(plan, pa, why_not)) return false;
+    pa.src_buf = 1;  // out
+    pa.dst_buf = 2;  // scratch
+    if (!make_cols_pass(plan, dim_index, best2, best1 * inner, pb, why_not, true)) return false;
+    if (std::string(pb.kernel_name) == "generic") {
+        why_not = "second factor only has a literal-stage kernel";
+        return false;
+    }
+    pb.src_buf = 2;
+    pb.dst_buf = 1;
+    if (pb.prepare && pb.prepare() != MIFFT_OK) return false;
+    const bool inv = plan.inverse != 0;
+    hipError_t e = upload_twiddle_table(plan.out_dtype, pa.N, inv, &pa.d_twiddle);
+    if (e == hipSuccess) e = upload_twiddle_table(plan.out_dtype, N, inv, &pa.d_aux);  // W_N^m for the k1 * n2 twiddle
+    if (e == hipSuccess) e = upload_twiddle_table(plan.out_dtype, pb.N, inv, &pb.d_twiddle);
+    if (e == hipSuccess) e = alloc_scratch(plan);
+    if (e != hipSuccess) {
+        free_pass_tables(pa);
+        free_pass_tables(pb);
+        why_not = std::string("device allocation: ") + hipGetErrorString(e);
+        plan.alloc_failed = true;
+        return false;
+    }
+    plan.passes.push_back(pa);
+    plan.passes.push_back(pb);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // A STRIDED dimension too long for a column tile (N > 4096: 8K-video columns, ...): transpose the
 // [N][inner] matrices into the plan scratch, run the contiguous-row kernel of length N there, transpose
 // back.  Three passes, each fully coalesced -- the reference's own transpose / FFT / transpose scheme

@@ -354,6 +354,14 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
             // literal-stage column fallback by an order of magnitude (and lift its 10 240-point limit)
             if (!ok && ps.inner != 1 && ps.N > 4096) {
                 std::string whyt;
+                // two column passes through the scratch (four-step) when both factors have fused tiles ...
+                if (build_fourstep_strided(p, i, whyt)) continue;
+                if (p.alloc_failed) {
+                    free_plan_device(p);
+                    delete h;
+                    return set_error(MIFFT_ERR_HIP, "four-step of strided dimension " + std::to_string(i) + ": " + whyt);
+                }
+                // ... else the reference's own route: transpose, contiguous-row kernel, transpose back
                 if (build_transposed_dim(p, i, ordered[i], processed[i], whyt)) continue;
                 if (p.alloc_failed) {  // out of device memory is an error, not a reason to try a slower kernel
                     free_plan_device(p);

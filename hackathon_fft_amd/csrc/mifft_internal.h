@@ -109,6 +109,10 @@ bool select_jit_plane(const Plan& plan, DimPass& pass, std::string& why_not);
 // the two innermost dimensions of images that fit one XCD's L2: rows, XCD-local barrier, columns from L2
 bool select_jit_image(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_jit_tstore(const Plan& plan, DimPass& pass, std::string& why_not);
+// first four-step pass of a strided dimension (TileCfg::FS1): pass.N = N1, pass.fs_n2 = N2
+bool select_jit_fs1(const Plan& plan, DimPass& pass, std::string& why_not);
+// a strided dimension beyond one column tile as two column passes through the plan scratch (kernels_fourstep.hip)
+bool build_fourstep_strided(Plan& plan, int dim_index, std::string& why_not);
 bool jit_tstore_feasible(const Plan& plan, int64_t n1, int64_t n2);
 bool jit_cols_feasible(const Plan& plan, int64_t n, int64_t inner);
 int jit_precompile(int in_dtype, int out_dtype, int64_t n, int cols, int in_real, size_t* code_bytes, std::string& why);

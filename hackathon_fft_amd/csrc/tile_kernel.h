@@ -103,6 +103,9 @@ struct TileParams {
     // starts with the lines written LAST, i.e. the ones most likely to be still in the 256-MiB Infinity Cache (LRU:
     // walking forward again would evict exactly the lines it is about to need).
     int reverse;
+    // FS1 configurations: `inner` is the LOAD row stride N2 * fs_inner; rows are stored at stride fs_inner
+    long long fs_inner;
+    long long fs_n2;
 };
 
 MIFFT_DEV long long tile_id(const TileParams& p, long long t) { return p.reverse ? p.n_tiles - 1 - t : t; }
@@ -118,7 +121,8 @@ enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
 
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
-          bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false, typename IT_ = T_, bool WSUB_ = false>
+          bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false, typename IT_ = T_, bool WSUB_ = false,
+          bool FS1_ = false>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -201,6 +205,14 @@ struct TileCfg {
     static constexpr bool XCD_CHUNK = COLS_ && TILE_ * 2 * (int)sizeof(T_) < 128;
 #endif
     static constexpr bool TSTORE = TSTORE_;
+    // FS1 (column tiles): first pass of the four-step of a STRIDED dimension of N = N1 * N2 points (N1 = this
+    // configuration's N).  The dimension is viewed as [N1][N2] rows of `fs_inner` contiguous elements; the tile of
+    // (n2, 16 columns) is transformed over n1 (row stride N2 * fs_inner) and its row k1 is stored, multiplied by
+    // W_N^(k1 * n2), as row n2 * N1 + k1 of the OTHER buffer -- a row-granular transposition, so the stores keep their
+    // TILE-element runs and need no LDS round trip.  The second pass (an ordinary column tile of N2 points at row
+    // stride N1 * fs_inner) then leaves the spectrum in natural order.
+    static constexpr bool FS1 = FS1_;
+    static_assert(!FS1_ || (COLS_ && FIRST_DIRECT_ && LAST_DIRECT_ && !TSTORE_ && !WSUB_), "FS1: a direct column tile");
     static constexpr int CPITCH = TSTORE_ ? TILE_ + 1 : TILE_;
     static_assert(!TSTORE_ || (COLS_ && !LAST_DIRECT_ && FIRST_DIRECT_), "TSTORE: column tile, last pass left in LDS");
     static constexpr int DATA_ELEMS = COLS_ ? N_ * CPITCH : LD * TILE_;
@@ -317,9 +329,27 @@ MIFFT_DEV void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// FS1: tile t = (outer o, n2, column tile): load base / store base / twiddle row n2
+template <class C>
+MIFFT_DEV void tile_geom_fs1(const TileParams& p, long long t, long long& base, long long& obase, int& nv, int& n2) {
+    const long long tiles_per_row = (p.fs_inner + C::TILE - 1) / C::TILE;
+    const long long o = t / p.tiles_per_outer, r = t - o * p.tiles_per_outer;
+    const long long row = r / tiles_per_row, c0 = (r - row * tiles_per_row) * C::TILE;
+    const long long left = p.fs_inner - c0;
+    nv = (int)(left < C::TILE ? left : C::TILE);
+    n2 = (int)row;
+    const long long image = o * (long long)C::N * p.inner;  // N1 * (N2 * fs_inner) elements per outer index
+    base = image + row * p.fs_inner + c0;
+    obase = image + row * (long long)C::N * p.fs_inner + c0;
+}
+
 template <class C>
 MIFFT_DEV void tile_geom(const TileParams& p, long long t, long long& base, int& nv) {
-    if constexpr (C::COLS) {
+    if constexpr (C::FS1) {
+        long long obase;
+        int n2;
+        tile_geom_fs1<C>(p, t, base, obase, nv, n2);
+    } else if constexpr (C::COLS) {
         const long long o = t / p.tiles_per_outer;
         const long long c0 = (t - o * p.tiles_per_outer) * C::TILE;
         const long long left = p.inner - c0;
@@ -374,6 +404,33 @@ MIFFT_DEV void fill_lds_tw(cpx<typename C::T>* ltw, const cpx<typename C::T>* tw
 #define MIFFT_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define MIFFT_FENCE() ((void)0)
+#endif
+
+// In-kernel phase stamps -- DIAGNOSTIC BUILDS ONLY (tools/tune, -DMIFFT_STAMPS; no product kernel executes one).
+// Thread 0 of every workgroup accumulates s_memtime deltas per phase in 17 LDS words BEHIND the kernel's dynamic LDS
+// (the tuner launches with 256 extra bytes) and copies them to the buffer passed in TileParams::tcol at the end
+// ([workgroup][16] shader cycles); stamp values never reach an output element.
+#ifdef MIFFT_STAMPS
+MIFFT_DEV void mifft_stamp(int i, unsigned lds_off, const void* dump = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_stamp[];  // the kernel's dynamic LDS
+    if (threadIdx.x == 0) {
+        unsigned long long* a = (unsigned long long*)(smem_stamp + ((lds_off + 15) / 16) * 16);
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (i < 0) {
+            for (int k = 0; k < 16; ++k) a[k] = 0;
+        } else if (i < 16) {
+            a[i] += t - a[16];
+        } else {
+            for (int k = 0; k < 16; ++k) ((unsigned long long*)dump)[(size_t)blockIdx.x * 16 + k] = a[k];
+        }
+        a[16] = __builtin_amdgcn_s_memtime();
+    }
+}
+#define MIFFT_STAMP(C_, i) mifft_stamp(i, (unsigned)C_::LDS_BYTES)
+#define MIFFT_STAMP_DUMP(C_, p_) mifft_stamp(99, (unsigned)C_::LDS_BYTES, (p_).tcol)
+#else
+#define MIFFT_STAMP(C_, i) ((void)0)
+#define MIFFT_STAMP_DUMP(C_, p_) ((void)0)
 #endif
 
 // gather the pass-0 inputs of tile (base, nv) from HBM into registers
@@ -466,7 +523,7 @@ MIFFT_DEV void pass_gather_lds(const TileParams& p, const cpx<typename C::T>* sr
 // registers -> butterflies -> Stockham scatter (LDS, or HBM for the last pass)
 template <class C, int I>
 MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds, cpx<typename C::T> (*v)[C::R(I)],
-                                    long long base, int nv, int tid) {
+                                    long long base, int nv, int tid, long long obase = 0, int fs_row = 0) {
     using T = typename C::T;
     using V = cpx<T>;
     constexpr int R = C::R(I), P = C::P(I), IPT = C::IPT(I);
@@ -481,7 +538,25 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
 #endif
             const int q = b / P, pp = b - q * P;
             const int o0 = q * P * R + pp;
-            if constexpr (DST_GLOBAL) {
+            if constexpr (DST_GLOBAL && C::FS1) {
+                if (c < nv) {
+                    // row k1 = o0 + s * P of this tile becomes row n2 * N1 + k1 of the other buffer, times W^(k1 * n2)
+                    const unsigned off = (unsigned)o0 * (unsigned)p.fs_inner + (unsigned)c;
+                    const long long step = (long long)P * p.fs_inner;  // uniform
+                    const V* wtab = (const V*)p.tlo;                    // W_(N1 N2)^m, m < N1 * N2
+#pragma unroll
+                    for (int s = 0; s < R; ++s) {
+                        V w = wtab[(o0 + s * P) * fs_row];
+                        if (p.inverse) w.y = -w.y;  // the plan's table is conjugated for inverse plans; forward W here
+                        V y = cmul(v[k][s], w);
+                        if (p.inverse) {
+                            y.x *= (T)p.scale;
+                            y.y *= -(T)p.scale;
+                        }
+                        gstore<(C::NT & 2) != 0>(gout + obase + s * step + off, y);
+                    }
+                }
+            } else if constexpr (DST_GLOBAL) {
                 if (c < nv) {
                     const unsigned off = lane_off<C>(p, c, o0);
                     const long long step = (long long)P * elem_stride<C>(p);  // uniform
@@ -599,10 +674,11 @@ MIFFT_DEV void bigprime_pass(cpx<typename C::T>* lds, const cpx<typename C::T>* 
 // TWSHIFT: extra offset of this configuration's LDS twiddle table (rectangular planes keep two tables)
 template <class C, int I, int TWSHIFT = 0>
 MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<typename C::T>* twr,
-                        cpx<typename C::T> (*pre)[C::R(0)], long long base, int nv, int tid) {
+                        cpx<typename C::T> (*pre)[C::R(0)], long long base, int nv, int tid, long long obase = 0,
+                        int fs_row = 0) {
     if constexpr (I < C::NP && C::BIGP(I)) {
         bigprime_pass<C, I>(lds, lds + C::DATA_ELEMS + TWSHIFT, lds + C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(I), tid);
-        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid);
+        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid, obase, fs_row);
     } else if constexpr (I < C::NP) {
         using T = typename C::T;
         using V = cpx<T>;
@@ -636,14 +712,17 @@ MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<
             else
                 wg_barrier<C>();
         }
-        pass_compute_scatter<C, I>(p, lds, v, base, nv, tid);
+        MIFFT_STAMP(C, 1 + 4 * I);  // gather (+ its barrier) of pass I: LDS reads / twiddles / wait for HBM loads
+        pass_compute_scatter<C, I>(p, lds, v, base, nv, tid, obase, fs_row);
+        MIFFT_STAMP(C, 2 + 4 * I);  // butterflies + scatter issue of pass I
         if constexpr (!DST_GLOBAL) {
             if constexpr (C::WSUB && I >= 1 && I < C::NP - 1)
                 wave_lds_fence();
             else
                 wg_barrier<C>();
         }
-        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid);
+        MIFFT_STAMP(C, 3 + 4 * I);  // barrier after the scatter of pass I
+        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid, obase, fs_row);
     }
 }
 
@@ -679,6 +758,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
         __syncthreads();
     }
 
+    MIFFT_STAMP(C, -1);
     V pre[C::PREFETCH ? C::IPT(0) : 1][C::R(0)];
     // this workgroup's tiles: t, t + t_step, ... < t_end
     long long t = blockIdx.x, t_end = p.n_tiles, t_step = gridDim.x;
@@ -711,7 +791,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
         long long base;
         int nv;
         const long long tt = tile_id(p, t);
-        tile_geom<C>(p, tt, base, nv);
+        long long obase = 0;
+        int fs_row = 0;
+        if constexpr (C::FS1)
+            tile_geom_fs1<C>(p, tt, base, obase, nv, fs_row);
+        else
+            tile_geom<C>(p, tt, base, nv);
         V cur[C::PREFETCH ? C::IPT(0) : 1][C::R(0)];
         if constexpr (C::PREFETCH) {
 #pragma unroll
@@ -763,7 +848,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             }
             __syncthreads();
         }
-        run_pass<C, 0>(p, lds, twr, cur, base, nv, tid);
+        MIFFT_STAMP(C, 0);  // tile bookkeeping + issue of the next tile's prefetch
+        run_pass<C, 0>(p, lds, twr, cur, base, nv, tid, obase, fs_row);
         if constexpr (C::TSTORE) {
             // transposed + twiddled flat store: out[o][c0 + c][k1] = tile[k1][c] * W^{k1 * (c0 + c)}
             const long long o = tt / p.tiles_per_outer;
@@ -880,6 +966,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             __syncthreads();
         }
     }
+    MIFFT_STAMP_DUMP(C, p);
 }
 
 

@@ -70,3 +70,26 @@ def test_cols_f64(n):
     truth = np.fft.fftn(to_complex(x), axes=(1, 2))
     assert rel_l2(out, from_complex(truth, np.float64)) < 1e-12, plan.kernel_name(0)
     assert plan.kernel_name(0) != "generic", n
+
+
+@pytest.mark.parametrize("n", [s for s in _gen.SIZES if s <= 128])
+@pytest.mark.parametrize("inner,width", [(64, 64), (96, 32)])
+def test_wide_cols(n, inner, width):
+    """strides that are a multiple of 32 / 64 columns take the wide tiles (256- / 512-byte runs)"""
+    rng = np.random.default_rng(n + inner)
+    x = rng.standard_normal((3, n, inner, 2)).astype(np.float32)
+    out, plan = _run(x)
+    name = plan.kernel_name(0)
+    if n * width <= 4096 or (width == 64 and n * 32 <= 4096):
+        assert "_w" in name or name.startswith("plane"), name   # (small n x inner planes are fused instead)
+    truth = np.fft.fftn(to_complex(x), axes=(1, 2))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32, name
+
+
+@pytest.mark.parametrize("n", [s for s in _gen.SIZES_F64 if s <= 128])
+def test_wide_cols_f64(n):
+    rng = np.random.default_rng(n + 5)
+    x = rng.standard_normal((2, n, 64, 2))
+    out, plan = _run(x)
+    truth = np.fft.fftn(to_complex(x), axes=(1, 2))
+    assert rel_l2(out, from_complex(truth, np.float64)) < 1e-12, plan.kernel_name(0)

@@ -383,10 +383,32 @@ def test_four_step_on_the_contiguous_dimension_of_an_nd_transform(shape, comps):
         assert rel_l2(back, x) < REL_L2_TOL_F32
 
 
-@pytest.mark.parametrize("shape", [(1, 7680, 64), (2, 5120, 40), (1, 8192, 3, 5), (1, 6144, 100), (2, 5000, 24), (1, 9000, 10)])
-def test_long_strided_dimension_through_transposes(shape):
-    """A strided dimension beyond the column-tile table (8K-video columns): transpose -> row kernel -> transpose
-    through the plan scratch."""
+LONG_STRIDED = [(1, 7680, 64), (2, 5120, 40), (1, 8192, 3, 5), (1, 6144, 100), (2, 5000, 24), (1, 9000, 10),
+                (1, 4320, 7680), (3, 16384, 16), (2, 2, 4608, 33)]
+
+
+@pytest.mark.parametrize("shape", LONG_STRIDED)
+def test_long_strided_dimension_four_step(shape):
+    """A strided dimension beyond the column-tile table (8K-video columns): two column passes through the plan scratch
+    (N = N1 * N2: FS1 tiles store row k1 of (n2, columns) as row n2 * N1 + k1 times W^(k1 n2), then N2-point tiles)."""
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape + (2,)).astype(np.float32)
+    out, plan = gpu_fft(x, out_dtype=np.float32)
+    long_dim = int(np.argmax(shape[1:]))
+    if long_dim < len(shape) - 2:
+        assert "_fs1" in plan.kernel_name(long_dim), plan.kernel_name(long_dim)
+        assert plan.scratch_bytes == x.nbytes
+    truth = np.fft.fftn(to_complex(x), axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
+    back, _ = gpu_fft(out, inverse=True, out_dtype=np.float32)
+    assert rel_l2(back, x) < REL_L2_TOL_F32
+
+
+@pytest.mark.parametrize("shape", [(1, 7680, 64), (2, 5000, 24), (1, 8192, 3, 5)])
+def test_long_strided_dimension_through_transposes(shape, monkeypatch):
+    """The fallback for such dimensions (MIFFT_FOURSTEP_STRIDED=0, or a factor without a fused column tile): the
+    reference's own route -- transpose -> row kernel -> transpose through the plan scratch."""
+    monkeypatch.setenv("MIFFT_FOURSTEP_STRIDED", "0")
     rng = np.random.default_rng(sum(shape))
     x = rng.standard_normal(shape + (2,)).astype(np.float32)
     out, plan = gpu_fft(x, out_dtype=np.float32)
@@ -395,3 +417,18 @@ def test_long_strided_dimension_through_transposes(shape):
     assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
     back, _ = gpu_fft(out, inverse=True, out_dtype=np.float32)
     assert rel_l2(back, x) < REL_L2_TOL_F32
+
+
+def test_scratch_allocation_failure_is_an_error_not_a_fallback(monkeypatch):
+    """A route that needs the plan scratch must report MIFFT_ERR_HIP when the device is out of memory -- not keep
+    half-built passes with a NULL scratch, and not hide the failure behind a slower kernel."""
+    monkeypatch.setenv("MIFFT_TEST_FAIL_SCRATCH_ALLOC", "1")
+    for fs in ("1", "0"):
+        monkeypatch.setenv("MIFFT_FOURSTEP_STRIDED", fs)
+        with pytest.raises(mf.MifftError) as e:
+            mf.plan_fft(torch.float32, torch.float32, (1, 7680, 64, 2), (1, 7680, 64, 2), ctx=mf.DeviceContext(0))
+        assert e.value.status == -11 and "device allocation" in e.value.message
+    monkeypatch.delenv("MIFFT_TEST_FAIL_SCRATCH_ALLOC")
+    monkeypatch.delenv("MIFFT_FOURSTEP_STRIDED")
+    plan = mf.plan_fft(torch.float32, torch.float32, (1, 7680, 64, 2), (1, 7680, 64, 2), ctx=mf.DeviceContext(0))
+    assert plan.scratch_bytes == 7680 * 64 * 8 and plan.num_launches == 3

@@ -34,6 +34,13 @@ struct Variant {
 
 static int g_cus = 256;
 static int g_wg_override = 0;
+#ifdef MIFFT_STAMPS
+static unsigned long long* g_stamps = nullptr;  // [grid][16] phase cycles of thread 0 (diagnostic build)
+static long long g_last_grid = 0, g_last_tiles = 0;
+#define STAMP_LDS 256
+#else
+#define STAMP_LDS 0
+#endif
 
 template <class C>
 Variant make(const char* name) {
@@ -64,7 +71,17 @@ Variant make(const char* name) {
             set = true;
         }
         long long grid = tile_grid<C>(g_cus, tp.n_tiles, g_wg_override);
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), C::LDS_BYTES, 0, tp);
+#ifdef MIFFT_STAMPS
+        tp.tcol = g_stamps;
+        g_last_grid = grid;
+        g_last_tiles = tp.n_tiles;
+        static bool set2 = false;
+        if (!set2) {
+            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + STAMP_LDS));
+            set2 = true;
+        }
+#endif
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), C::LDS_BYTES + STAMP_LDS, 0, tp);
     };
     return v;
 }
@@ -586,6 +603,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dout, bytes));
     CK(hipMalloc(&dref, bytes));
     CK(hipMalloc(&dtw, tw.size() * 4));
+#ifdef MIFFT_STAMPS
+    CK(hipMalloc(&g_stamps, 4096 * 16 * 8));
+#endif
     CK(hipMemcpy(din, h.data(), bytes, hipMemcpyHostToDevice));
     CK(hipMemcpy(dtw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
 
@@ -659,6 +679,28 @@ int main(int argc, char** argv) {
             }
         }
     }
+#ifdef MIFFT_STAMPS
+    {
+        std::vector<unsigned long long> hs(4096 * 16);
+        for (size_t i = 0; i < vs.size(); ++i) {
+            CK(hipMemset(g_stamps, 0, 4096 * 16 * 8));
+            prep(dout);
+            vs[i].run(inplace ? dout : din, dout, dtw, batch, outer, inner);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(hs.data(), g_stamps, 4096 * 16 * 8, hipMemcpyDeviceToHost));
+            double ph[16] = {0};
+            for (long long g = 0; g < g_last_grid; ++g)
+                for (int k = 0; k < 16; ++k) ph[k] += (double)hs[g * 16 + k];
+            printf("%-28s cycles per tile (thread 0):", vs[i].name.c_str());
+            double tot = 0;
+            for (int k = 0; k < 14; ++k) {
+                printf(" [%d]%6.0f", k, ph[k] / (double)g_last_tiles);
+                tot += ph[k] / (double)g_last_tiles;
+            }
+            printf("  sum %6.0f\n", tot);
+        }
+    }
+#endif
     printf("GROUP %d  N=%d  tensor %.1f MB  (wg/cu override %d)\n", GROUP, N, bytes / 1e6, g_wg_override);
     printf("%-28s %9s %9s %8s %8s %10s\n", "variant", "min ms", "mean ms", "GB/s", "frac8T", "relerr");
     for (size_t i = 0; i < vs.size(); ++i) {
