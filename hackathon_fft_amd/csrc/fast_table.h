@@ -78,6 +78,15 @@ struct FastEntry {
 
 
 #define MIFFT_CFG(...) MIFFT_CFG_X(false, false, 0, -1, __VA_ARGS__)
+// column tile whose passes 1..NP-1 run inside wave-owned sub-problems (TileCfg::WSUB): R0 a multiple of THREADS / 64
+#define MIFFT_CFG_WSUB(NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                        \
+    {                                                                                                                          \
+        false, false, -1, DT, N, COLS, NAME,                                                                                   \
+            launch_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, false, false, 0, false, T, true>>,   \
+            prepare_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, false, false, 0, false, T, true>>,  \
+            TILE, THREADS,                                                                                                     \
+            TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, false, false, 0, false, T, true>::LDS_BYTES       \
+    }
 // complex-input kernel + its real-input twin (contiguous dimension only)
 #define MIFFT_CFG_CR(NAME, ...) \
     MIFFT_CFG_X(false, false, 0, -1, NAME, __VA_ARGS__), MIFFT_CFG_X(false, true, 0, -1, NAME "_r", __VA_ARGS__)

@@ -35,8 +35,11 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_CR("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_CR("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     // ---- strided dimensions, fp32 (in place, LDS column tiles) ----
-    MIFFT_CFG("cols640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
-    MIFFT_CFG("cols480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+    // ten waves, one per sub-problem of the radix-10 first pass (WSUB): the 8 x 8 passes exchange without workgroup
+    // barriers, the waves drift apart and overlap each other's HBM traffic; with the next tile's loads issued in slices
+    // between the passes 0.1009 -> 0.0969 ms for 100 x 640 x 480 (tools/tune GROUP 20)
+    MIFFT_CFG_WSUB("cols640_10x8x8_ws", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_LDS, 1, true),
+    MIFFT_CFG_WSUB("cols480_10x6x8_ws", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 16, 640, true, true, true, TW_LDS, 1, true),
     // 16 columns x 1024 points = 128 KiB: the four-step passes of 2^20-point transforms (0.266 vs 0.349 ms for
     // the generated 8-column tile at 64 x 2^20)
     MIFFT_CFG("cols1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
@@ -164,6 +167,10 @@ using Plane64R = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, 
 using Plane64C = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, true, false, true, TW_LDS, 2, false>;
 using Plane128R = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true>;
 using Plane128C = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false>;
+// wave-private variant: radix 8 first (pass 0 reads 128-byte runs), the next plane's loads sliced between the passes:
+// 1280 planes 0.0688 ms against 0.0711 for 16 x 8 (tools/tune GROUP 7)
+using Plane128WR = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true>;
+using Plane128WC = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false>;
 using Plane64RN = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false, 0, false, false, 1>;
 // (a non-temporal twin of the 128 x 128 plane measured SLOWER: 75.5 -> 80.5 us for 1280 planes; its next-plane
 //  register prefetch already keeps the loads far ahead)
@@ -175,8 +182,8 @@ static const PlaneEntry kPlaneTable[] = {
      512, Plane64R::LDS_BYTES},
     // wave-private exchanges (plane_kernel_wp): 2 workgroup barriers per plane instead of 12; 1280 planes 0.0812 ->
     // 0.0744 ms (tools/tune GROUP 7).  For 64 x 64 planes (four workgroups per CU already overlap) it ties.
-    {false, MIFFT_F32, 128, 128, "plane128x128_16x8_wp", launch_plane_wp<Plane128R, Plane128C, 8>,
-     prepare_plane_wp<Plane128R, Plane128C, 8>, 1024, WavePlane<Plane128R, Plane128C, 8>::LDS_BYTES},
+    {false, MIFFT_F32, 128, 128, "plane128x128_8x16_wp", launch_plane_wp<Plane128WR, Plane128WC, 8>,
+     prepare_plane_wp<Plane128WR, Plane128WC, 8>, 1024, WavePlane<Plane128WR, Plane128WC, 8>::LDS_BYTES},
 };
 
 bool select_fast_plane(const Plan& plan, DimPass& pass) {

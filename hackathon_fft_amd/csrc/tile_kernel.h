@@ -324,6 +324,13 @@ MIFFT_DEV bool item_of(int tid, int k, int& c, int& b) {
 
 // order one wave's LDS accesses across a pass boundary for the COMPILER (the hardware executes one wave's LDS
 // instructions in order; there is nothing to wait for)
+// every vector-memory operation of this wave issued so far is complete (s_waitcnt vmcnt(0), visible to the compiler's
+// own wait-count bookkeeping) and nothing scheduled after it moves above
+MIFFT_DEV void vm_drain() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // gfx9 encoding: vmcnt = 0, expcnt / lgkmcnt unconstrained
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 MIFFT_DEV void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -433,8 +440,9 @@ MIFFT_DEV void mifft_stamp(int i, unsigned lds_off, const void* dump = nullptr) 
 #define MIFFT_STAMP_DUMP(C_, p_) ((void)0)
 #endif
 
-// gather the pass-0 inputs of tile (base, nv) from HBM into registers
-template <class C>
+// gather the pass-0 inputs of tile (base, nv) from HBM into registers; slice PART of NPARTS: the elements e = k R + j
+// with e % NPARTS == PART (NPARTS = 1: all of them)
+template <class C, int PART = 0, int NPARTS = 1>
 MIFFT_DEV void load_pass0(const TileParams& p, cpx<typename C::T> (*v)[C::R(0)], long long base, int nv, int tid) {
     using T = typename C::T;
     using V = cpx<T>;
@@ -455,6 +463,7 @@ MIFFT_DEV void load_pass0(const TileParams& p, cpx<typename C::T> (*v)[C::R(0)],
             const long long step = (long long)NB * elem_stride<C>(p);  // uniform: element j sits j*step further
 #pragma unroll
             for (int j = 0; j < R; ++j) {
+                if ((k * R + j) % NPARTS != PART) continue;  // (compile-time after unrolling)
                 if constexpr (!same_t<typename C::IT, T>::value) {
                     v[k][j] = load_foreign<C>(p.in, base + j * step + off);
                 } else if constexpr (C::IN_REAL) {
@@ -671,14 +680,47 @@ MIFFT_DEV void bigprime_pass(cpx<typename C::T>* lds, const cpx<typename C::T>* 
     __syncthreads();
 }
 
+// 1: the next tile's HBM loads are issued in slices between the passes of the current tile; 0: all at the top
+#ifndef MIFFT_SLICED_PREFETCH
+#define MIFFT_SLICED_PREFETCH 1
+#endif
+#ifndef MIFFT_SLICED_PREFETCH_PLANE
+#define MIFFT_SLICED_PREFETCH_PLANE 1
+#endif
+
+template <int K>
+struct IntC {
+    static constexpr int value = K;
+};
+
+struct NoHook {
+    MIFFT_DEV void operator()() const {}
+    template <int K>
+    MIFFT_DEV void operator()(IntC<K>) const {}
+};
+
 // TWSHIFT: extra offset of this configuration's LDS twiddle table (rectangular planes keep two tables)
-template <class C, int I, int TWSHIFT = 0>
+// `before_stores` runs once per tile, after the last LDS read and right BEFORE the butterflies + HBM stores of the last
+// pass: the prefetching kernels wait there for the next tile's inputs (loads issued a whole tile earlier: the wait is
+// free).  vmcnt counts loads and stores together and the compiler's s_waitcnt insertion cannot count the exec-masked
+// stores, so without this the wait for the prefetched registers -- at the top of the next iteration -- was a vmcnt(0):
+// it waited for every store of the tile just finished before the next loads were even issued (29 % of the tile period
+// of the 640-point column tile by in-kernel stamps).  After an explicit, compiler-visible vmcnt(0) ahead of the stores
+// the registers are known to be loaded and the top-of-loop copy needs no wait at all.
+// `between(IntC<K>)` runs at the seams of the tile: K = 2 I + 1 behind the barrier that follows the scatter of pass I,
+// K = 2 I behind the barrier that follows the gather of pass I (1 <= I < NP - 1).  The prefetching kernels issue the
+// next tile's HBM loads there in SLICES.  Issued in one burst (at the top of the tile, or anywhere else) the 20 loads
+// per thread of a 640-point column tile take ~5 000 cycles to be ACCEPTED -- every wave of the one workgroup a CU holds
+// sits in that issue stall at once, and nothing computes meanwhile (in-kernel stamps: the stall moves with the burst,
+// 4 500 of 16 600 cycles per tile).  A few loads per seam keep the vector-memory queue short, the waves go on to their
+// butterflies, and the memory system sees a steady stream instead of load / compute / store phases.
+template <class C, int I, int TWSHIFT = 0, class Hook = NoHook, class Hook0 = NoHook>
 MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<typename C::T>* twr,
                         cpx<typename C::T> (*pre)[C::R(0)], long long base, int nv, int tid, long long obase = 0,
-                        int fs_row = 0) {
+                        int fs_row = 0, Hook before_stores = Hook(), Hook0 between = Hook0()) {
     if constexpr (I < C::NP && C::BIGP(I)) {
         bigprime_pass<C, I>(lds, lds + C::DATA_ELEMS + TWSHIFT, lds + C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(I), tid);
-        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid, obase, fs_row);
+        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid, obase, fs_row, before_stores, between);
     } else if constexpr (I < C::NP) {
         using T = typename C::T;
         using V = cpx<T>;
@@ -711,8 +753,10 @@ MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<
                 wave_lds_fence();
             else
                 wg_barrier<C>();
+            if constexpr (I < C::NP - 1) between(IntC<2 * I>{});
         }
         MIFFT_STAMP(C, 1 + 4 * I);  // gather (+ its barrier) of pass I: LDS reads / twiddles / wait for HBM loads
+        if constexpr (I == C::NP - 1) before_stores();
         pass_compute_scatter<C, I>(p, lds, v, base, nv, tid, obase, fs_row);
         MIFFT_STAMP(C, 2 + 4 * I);  // butterflies + scatter issue of pass I
         if constexpr (!DST_GLOBAL) {
@@ -722,7 +766,8 @@ MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<
                 wg_barrier<C>();
         }
         MIFFT_STAMP(C, 3 + 4 * I);  // barrier after the scatter of pass I
-        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid, obase, fs_row);
+        if constexpr (!DST_GLOBAL && I < C::NP - 1) between(IntC<2 * I + 1>{});
+        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid, obase, fs_row, before_stores, between);
     }
 }
 
@@ -770,6 +815,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             t_end = (x + 1) * p.n_tiles / 8;
         }
     }
+    static_assert(!(C::PREFETCH && C::BIGP0), "prefetching kernels read pass 0 straight from HBM");
     if constexpr (C::PREFETCH) {
         if (t < t_end) {
             long long base;
@@ -798,19 +844,38 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
         else
             tile_geom<C>(p, tt, base, nv);
         V cur[C::PREFETCH ? C::IPT(0) : 1][C::R(0)];
+        // seams between passes where a slice of the next tile's loads can go: 2 NP - 3 of them, plus the top
+        // (column tiles only: row tiles measured 4-8 % SLOWER sliced -- rows480 0.096 -> 0.104 ms, tools/tune GROUP 5 --
+        //  while 640- and 1024-point column tiles gain 4-6 %)
+        constexpr int SLICES = (C::PREFETCH && C::COLS && MIFFT_SLICED_PREFETCH && C::NP > 1) ? 2 * C::NP - 2 : 1;
+        const long long tn = t + t_step;
+        long long nbase = 0;
+        int nnv = 0;
         if constexpr (C::PREFETCH) {
 #pragma unroll
             for (int k = 0; k < C::IPT(0); ++k)
 #pragma unroll
                 for (int j = 0; j < C::R(0); ++j) cur[k][j] = pre[k][j];
-            const long long tn = t + t_step;
-            if (tn < t_end) {  // issue the next tile's HBM reads before this tile's arithmetic
-                long long nbase;
-                int nnv;
-                tile_geom<C>(p, tile_id(p, tn), nbase, nnv);
-                load_pass0<C>(p, pre, nbase, nnv, tid);
+            if (tn < t_end) tile_geom<C>(p, tile_id(p, tn), nbase, nnv);
+            if constexpr (SLICES == 1) {
+                if (tn < t_end) load_pass0<C>(p, pre, nbase, nnv, tid);  // all of the next tile's HBM reads at once
+            } else {
+                if (tn < t_end) load_pass0<C, 0, SLICES>(p, pre, nbase, nnv, tid);
             }
         }
+        // the other slices of the next tile's loads, one per seam between the passes (see run_pass)
+        auto slice = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            if constexpr (C::PREFETCH && SLICES > 1 && K >= 1 && K < SLICES) {
+                if (tn < t_end) load_pass0<C, K, SLICES>(p, pre, nbase, nnv, tid);
+            }
+        };
+        // Run by the last pass right before its stores (see run_pass): the next tile's inputs were issued during this
+        // tile, so waiting for them HERE costs little -- and it keeps the compiler's wait for them (at the copy above,
+        // next iteration) from landing behind this tile's stores.
+        auto drain = [&]() {
+            if constexpr (C::PREFETCH) vm_drain();
+        };
         if constexpr (!C::FIRST_DIRECT && C::COLS) {
             // column tile staged in LDS (only the big-prime pass 0 needs this): runs of TILE adjacent columns
             static_assert(C::BIGP0, "column tiles load directly unless pass 0 works in LDS");
@@ -849,7 +914,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             __syncthreads();
         }
         MIFFT_STAMP(C, 0);  // tile bookkeeping + issue of the next tile's prefetch
-        run_pass<C, 0>(p, lds, twr, cur, base, nv, tid, obase, fs_row);
+        run_pass<C, 0>(p, lds, twr, cur, base, nv, tid, obase, fs_row, drain, slice);
         if constexpr (C::TSTORE) {
             // transposed + twiddled flat store: out[o][c0 + c][k1] = tile[k1][c] * W^{k1 * (c0 + c)}
             const long long o = tt / p.tiles_per_outer;
@@ -1030,9 +1095,12 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel(const Tile
             const long long tn = t + gridDim.x;
             if (tn < p.n_tiles) load_pass0<CR>(p, pre, tile_id(p, tn) * PLANE, CR::TILE, tid);
         }
+        auto drain = [&]() {  // before the column side's HBM stores: see tile_kernel / run_pass
+            if constexpr (CR::PREFETCH) vm_drain();
+        };
         run_pass<CR, 0>(p, lds, twr, cur, base, CR::TILE, tid);  // rows: HBM -> ... -> LDS (natural order)
         V none[1][CC::R(0)];
-        run_pass<CC, 0, CSHIFT>(p, lds, twr, none, base, CC::TILE, tid);  // columns: LDS -> ... -> HBM
+        run_pass<CC, 0, CSHIFT>(p, lds, twr, none, base, CC::TILE, tid, 0, 0, drain);  // columns: LDS -> ... -> HBM
     }
 }
 
@@ -1075,7 +1143,7 @@ struct WavePlane {
     }
 };
 
-template <class CR, class CC, int PAD>
+template <class CR, class CC, int PAD, int PART = 0, int NPARTS = 1>
 MIFFT_DEV void wp_load_rows(const TileParams& p, cpx<typename CR::T> (*v)[CR::R(0)], long long base, int wave, int lane) {
     using G = WavePlane<CR, CC, PAD>;
     using V = cpx<typename CR::T>;
@@ -1086,13 +1154,14 @@ MIFFT_DEV void wp_load_rows(const TileParams& p, cpx<typename CR::T> (*v)[CR::R(
         const int sub = k * 64 + lane, rl = sub / NB, b = sub - rl * NB;
         const unsigned off = (unsigned)(wave * G::RPW + rl) * (unsigned)G::N2 + (unsigned)b;
 #pragma unroll
-        for (int j = 0; j < R; ++j) v[k][j] = gload<(CR::NT & 1) != 0>(gin + base + j * NB + off);
+        for (int j = 0; j < R; ++j)
+            if ((k * R + j) % NPARTS == PART) v[k][j] = gload<(CR::NT & 1) != 0>(gin + base + j * NB + off);
     }
 }
 
-template <class CR, class CC, int PAD, int I>
+template <class CR, class CC, int PAD, int I, class Hook>
 MIFFT_DEV void wp_row_passes(const TileParams& p, cpx<typename CR::T>* lds, cpx<typename CR::T> (*pre)[CR::R(0)], int wave,
-                             int lane) {
+                             int lane, Hook between) {
     if constexpr (I < CR::NP) {
         using G = WavePlane<CR, CC, PAD>;
         using T = typename CR::T;
@@ -1134,12 +1203,14 @@ MIFFT_DEV void wp_row_passes(const TileParams& p, cpx<typename CR::T>* lds, cpx<
             }
         }
         wave_lds_fence();
-        wp_row_passes<CR, CC, PAD, I + 1>(p, lds, pre, wave, lane);
+        if constexpr (I == 0) between(IntC<1>{});
+        wp_row_passes<CR, CC, PAD, I + 1>(p, lds, pre, wave, lane, between);
     }
 }
 
-template <class CR, class CC, int PAD, int I>
-MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long long base, int wave, int lane) {
+template <class CR, class CC, int PAD, int I, class Hook, class Hook2>
+MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long long base, int wave, int lane,
+                             Hook before_stores, Hook2 between) {
     if constexpr (I < CC::NP) {
         using G = WavePlane<CR, CC, PAD>;
         using T = typename CR::T;
@@ -1160,10 +1231,12 @@ MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long
                 for (int j = 1; j < R; ++j) v[k][j] = cmul(v[k][j], ltw[CC::TWL_OFF(I) + (j - 1) * P + pp]);
             }
         }
-        if constexpr (I == CC::NP - 1)
+        if constexpr (I == CC::NP - 1) {
             __syncthreads();  // last LDS read of this plane: the next plane's row passes may overwrite the buffer
-        else
+            before_stores();  // wait for the prefetched plane ahead of the HBM stores (run_pass)
+        } else {
             wave_lds_fence();
+        }
         V* gout = (V*)p.out;
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
@@ -1187,7 +1260,8 @@ MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long
             }
         }
         if constexpr (I < CC::NP - 1) wave_lds_fence();
-        wp_col_passes<CR, CC, PAD, I + 1>(p, lds, base, wave, lane);
+        if constexpr (I == 0 && CC::NP > 1) between(IntC<3>{});
+        wp_col_passes<CR, CC, PAD, I + 1>(p, lds, base, wave, lane, before_stores, between);
     }
 }
 
@@ -1229,10 +1303,24 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const T
 #pragma unroll
             for (int j = 0; j < CR::R(0); ++j) cur[k][j] = pre[k][j];
         const long long tn = t + gridDim.x;
-        if (CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD>(p, pre, tile_id(p, tn) * PLANE, wave, lane);
-        wp_row_passes<CR, CC, PAD, 0>(p, lds, cur, wave, lane);
+        // the next plane's loads in four slices: here, behind the first row exchange, behind the hand-over barrier and
+        // behind the first column exchange (see run_pass: a burst of loads stalls every wave in its issue)
+        constexpr int SLICES = (CR::PREFETCH && MIFFT_SLICED_PREFETCH_PLANE) ? 4 : 1;
+        const long long nbase = tn < p.n_tiles ? tile_id(p, tn) * PLANE : 0;
+        if (CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD, 0, SLICES>(p, pre, nbase, wave, lane);
+        auto slice = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            if constexpr (CR::PREFETCH && SLICES > 1 && K >= 1 && K < SLICES) {
+                if (tn < p.n_tiles) wp_load_rows<CR, CC, PAD, K, SLICES>(p, pre, nbase, wave, lane);
+            }
+        };
+        auto drain = [&]() {  // ahead of this plane's HBM stores (tile_kernel / run_pass)
+            if constexpr (CR::PREFETCH) vm_drain();
+        };
+        wp_row_passes<CR, CC, PAD, 0>(p, lds, cur, wave, lane, slice);
         __syncthreads();  // hand-over: every row is complete before any column starts
-        wp_col_passes<CR, CC, PAD, 0>(p, lds, base, wave, lane);
+        slice(IntC<2>{});
+        wp_col_passes<CR, CC, PAD, 0>(p, lds, base, wave, lane, drain, slice);
         if (!CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD>(p, pre, tile_id(p, tn) * PLANE, wave, lane);
     }
 }
