@@ -16,6 +16,7 @@ from __future__ import annotations
 import collections
 import ctypes
 import enum
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -258,14 +259,25 @@ def _as_interleaved(x: "torch.Tensor"):
 
 _PLAN_CACHE: "collections.OrderedDict" = collections.OrderedDict()
 _PLAN_CACHE_SIZE = 32
+_PLAN_CACHE_LOCK = threading.RLock()
 
 
 def _cached_plan(in_dtype, out_dtype, in_shape, out_shape, radices, inverse, faithful_stages, device) -> Plan:
     """Plans of the convenience wrappers are kept (LRU): a plan is a few small device tables, building one
-    costs a hipMalloc + copy per dimension, and its tables must outlive the kernels enqueued with it."""
+    costs a hipMalloc + copy per dimension, and its tables must outlive the kernels enqueued with it.
+
+    A plan may own mutable device state that its execs share (the scratch tensor of the long-strided and three-launch
+    four-step routes, the counters of the opt-in image kernel), so the C ABI allows ONE exec in flight per plan
+    (include/mifft.h).  Execs are ordered on a stream; the cache therefore keeps one plan PER STREAM -- two streams (or
+    two threads on their own streams) transforming the same shape never share a plan -- and is guarded by a lock."""
+    with _PLAN_CACHE_LOCK:
+        return _cached_plan_locked(in_dtype, out_dtype, in_shape, out_shape, radices, inverse, faithful_stages, device)
+
+
+def _cached_plan_locked(in_dtype, out_dtype, in_shape, out_shape, radices, inverse, faithful_stages, device) -> Plan:
     key = (in_dtype, out_dtype, in_shape, out_shape,
            None if radices is None else tuple(tuple(int(b) for b in r) for r in radices),
-           bool(inverse), bool(faithful_stages), device)
+           bool(inverse), bool(faithful_stages), device, int(torch.cuda.current_stream(device).cuda_stream))
     plan = _PLAN_CACHE.get(key)
     if plan is None:
         try:
@@ -304,10 +316,11 @@ def _prime_factors(n: int) -> list:
 
 
 def clear_plan_cache() -> None:
-    for plan in _PLAN_CACHE.values():
-        torch.cuda.synchronize(plan.device)
-        plan.close()
-    _PLAN_CACHE.clear()
+    with _PLAN_CACHE_LOCK:
+        for plan in _PLAN_CACHE.values():
+            torch.cuda.synchronize(plan.device)
+            plan.close()
+        _PLAN_CACHE.clear()
 
 
 def _run(x: "torch.Tensor", *, radices, inverse: bool, out_dtype, faithful_stages: bool) -> "torch.Tensor":
@@ -324,7 +337,9 @@ def _run(x: "torch.Tensor", *, radices, inverse: bool, out_dtype, faithful_stage
 
 def fftn(x: "torch.Tensor", radices=None, *, out_dtype=None, faithful_stages: bool = False) -> "torch.Tensor":
     """Forward C2C transform over every dim but the first (batch).  ``x``: complex
-    ``(batch, d0..)`` or real-typed interleaved ``(batch, d0.., 2)``; ``radices``: one list per dim."""
+    ``(batch, d0..)`` or real-typed interleaved ``(batch, d0.., 2)``; ``radices``: one list per dim.
+    Asynchronous on the current torch stream; plans are cached per (shape, dtype, radices, device, stream), so
+    concurrent streams never share a plan's scratch (one exec in flight per plan, include/mifft.h)."""
     return _run(x, radices=radices, inverse=False, out_dtype=out_dtype, faithful_stages=faithful_stages)
 
 

@@ -252,6 +252,21 @@ def test_convenience_wrappers():
     assert len(api._PLAN_CACHE) == api._PLAN_CACHE_SIZE
     mf.clear_plan_cache()
     assert len(api._PLAN_CACHE) == 0
+    # one cached plan PER STREAM: a plan's scratch / counters allow one exec in flight, so two streams transforming the
+    # same shape must not share one
+    big = torch.from_numpy(rng.standard_normal((1, 5120, 8)) + 1j * rng.standard_normal((1, 5120, 8))).to(DEV)
+    ref = np.fft.fftn(big.cpu().numpy(), axes=(1, 2))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for st in (s1, s2, s1, s2):
+        with torch.cuda.stream(st):
+            outs.append(mf.fftn(big))           # the long strided dimension runs through the plan-owned scratch
+    torch.cuda.synchronize()
+    assert len(api._PLAN_CACHE) == 2
+    for o in outs:
+        np.testing.assert_allclose(o.cpu().numpy(), ref, atol=1e-8)
+    mf.clear_plan_cache()
 
 
 # ---- full BASELINE sizes: properties that need no CPU reference ----------------------------
