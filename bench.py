@@ -489,7 +489,27 @@ def worker(args, json_out):
         del main
         b.torch.cuda.empty_cache()
         if not args.no_strong_leg and name == DEFAULT_WORKLOAD and args.dtype == "f32" and not args.faithful:
-            result["strong_config5"] = b.strong_leg(max(10, min(args.steps, 100)), max(2, min(args.warmup, 10)))
+            # The headline above is complete; the strong-scaling leg is an extra object and must never cost the line.
+            # It is the only part of the run with point-to-point traffic between GPUs, so a watchdog bounds it: if it
+            # has not finished in time, every rank leaves (rank 0 prints the line without the leg first).
+            import threading
+
+            def bail():
+                if b.rank == 0:
+                    result["strong_config5"] = {"error": "strong-scaling leg did not finish within 120 s; skipped"}
+                    json_out.write(json.dumps(result) + "\n")
+                    json_out.flush()
+                os._exit(0)
+
+            watchdog = threading.Timer(120.0, bail)
+            watchdog.daemon = True
+            watchdog.start()
+            try:
+                result["strong_config5"] = b.strong_leg(max(10, min(args.steps, 100)), max(2, min(args.warmup, 10)))
+            except Exception as e:  # an RCCL / allocation error in the extra leg is reported, not fatal
+                result["strong_config5"] = {"error": repr(e)[:300]}
+            finally:
+                watchdog.cancel()
         if b.world == 1 and not args.no_configs and name == DEFAULT_WORKLOAD and args.dtype == "f32" and not args.faithful:
             cfgs = []
             for w in OTHER_BASELINE_CONFIGS:

@@ -69,13 +69,16 @@ struct FastEntry {
     size_t lds;
 };
 
-#define MIFFT_CFG_X(TS, REAL, NTM, STREAM, NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                         \
-    {                                                                                                               \
-        TS, REAL, STREAM, DT, N, COLS, NAME, launch_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM, TS>>,   \
-            prepare_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM, TS>>, \
-            TILE, THREADS, TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM, TS>::LDS_BYTES       \
+#define MIFFT_TILECFG(TS, REAL, NTM, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF) \
+    TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM, TS>
+#define MIFFT_CFG_X(TS, REAL, NTM, STREAM, NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF) \
+    {                                                                                                                      \
+        TS, REAL, STREAM, DT, N, COLS, NAME,                                                                               \
+            launch_tile<MIFFT_TILECFG(TS, REAL, NTM, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)>,  \
+            prepare_tile<MIFFT_TILECFG(TS, REAL, NTM, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)>, \
+            TILE, THREADS,                                                                                                 \
+            MIFFT_TILECFG(TS, REAL, NTM, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)::LDS_BYTES     \
     }
-
 
 #define MIFFT_CFG(...) MIFFT_CFG_X(false, false, 0, -1, __VA_ARGS__)
 // column tile whose passes 1..NP-1 run inside wave-owned sub-problems (TileCfg::WSUB): R0 a multiple of THREADS / 64

@@ -332,11 +332,13 @@ bool build_fourstep_strided(Plan& plan, int dim_index, std::string& why_not) {
             why_not = "MIFFT_FOURSTEP_STRIDED=0";
             return false;
         }
-    // most balanced factorisation whose factors both have a fused column configuration
-    int64_t best1 = 0, best2 = 0;
+    // most balanced factorisation whose factors both have a fused column configuration (MIFFT_FS_N1 forces the first
+    // factor: tuning knob)
+    int64_t best1 = 0, best2 = 0, forced1 = 0;
+    if (const char* e = getenv("MIFFT_FS_N1")) forced1 = atoll(e);
     double best_score = 1e300;
     for (int64_t n1 = 2; n1 <= 4096 && n1 < N; ++n1) {
-        if (N % n1) continue;
+        if (N % n1 || (forced1 > 0 && n1 != forced1)) continue;
         const int64_t n2 = N / n1;
         if (n2 > 4096 || n2 < 2) continue;
         if (!jit_cols_feasible(plan, n1, n2 * inner)) continue;

@@ -122,7 +122,7 @@ enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
           bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false, typename IT_ = T_, bool WSUB_ = false,
-          bool FS1_ = false, int SKEW_ = 0>
+          bool FS1_ = false>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -141,14 +141,7 @@ struct TileCfg {
     // N = 93 flat copy 0.173 -> 0.247 ms, 640-point column tiles 0.114 -> 0.139 ms), so it is a twin
     // configuration chosen at plan time by tensor size.
     static constexpr int NT = NT_;
-    // ROWS, lengths that are not a power of two (no XOR swizzle): one pad element after every SKEW elements of a row.
-    // The pass-0 scatter writes positions b * R0 + s for consecutive butterflies b: a lane stride of R0 elements, which
-    // for even R0 maps lanes b and b + 16 / gcd(R0, 16) onto the same banks (480 = 10 * 6 * 8: 2-way conflicts on every
-    // ds_write_b64 of pass 0, 19.5 % of the kernel's LDS cycles).  SKEW = R0 * 16 / gcd(R0, 16) shifts the second half
-    // of the lanes by one element (two banks) and the later passes' contiguous reads are unaffected.
-    static constexpr int SKEW = SKEW_;
-    static_assert(SKEW_ == 0 || !COLS_, "SKEW: contiguous-dimension tiles only");
-    static constexpr int LD = N_ + ROWPAD_ + (SKEW_ > 0 ? (N_ - 1) / SKEW_ : 0);  // ROWS: LDS pitch of one transform
+    static constexpr int LD = N_ + ROWPAD_;  // ROWS: LDS pitch of one transform
     static constexpr int R(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : i == 2 ? R2_ : R3_; }
     static constexpr int P(int i) {
         int p = 1;
@@ -271,8 +264,6 @@ template <class C, int E>
 MIFFT_DEV int lds_index(int c, int n) {
     if constexpr (C::COLS)
         return n * C::CPITCH + c;
-    else if constexpr (C::SKEW > 0)
-        return c * C::LD + n + n / C::SKEW;
     else
         return c * C::LD + swz<C, E>(n);
 }

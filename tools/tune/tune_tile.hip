@@ -194,8 +194,6 @@ Variant make_plane_wp(const char* name) {
 #define V(NAME, ...) make<TileCfg<__VA_ARGS__>>(NAME)
 // wave-owned sub-problems after pass 0 (TileCfg::WSUB)
 #define VW(NAME, ...) make<TileCfg<__VA_ARGS__, 0, false, false, 0, false, float, true>>(NAME)
-// in-row skew of the LDS layout (TileCfg::SKEW), with NT mode
-#define VS(NAME, NT, SKEW, ...) make<TileCfg<__VA_ARGS__, 0, false, false, NT, false, float, false, false, SKEW>>(NAME)
 // explicit non-temporal mode: ... PF, then NT (0 none, 1 loads, 2 stores, 3 both)
 #define VN(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, false, false, NT>>(NAME)
 // ... with an LDS row pad (ROWS: pitch = N + PAD)
@@ -310,12 +308,6 @@ int main(int argc, char** argv) {
         V("r480 16x30 t8 256 lds w2", float, 480, 2, 16, 30, 1, 1, 8, 256, false, true, true, TW_LDS, 2, false),
         V("r480 4x4x30 t8 256 lds w2", float, 480, 3, 4, 4, 30, 1, 8, 256, false, true, true, TW_LDS, 2, false),
         V("r480 10x6x8 t8 256 lds w2 pf", float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
-        VS("r480 10x6x8 t8 256 pf skew80", 0, 80, float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
-        VS("r480 10x6x8 t8 256 pf skew40", 0, 40, float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
-        VS("r480 10x6x8 t8 256 pf skew16", 0, 16, float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
-        VS("r480 10x6x8 t8 256 pf sk80 nt1", 1, 80, float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
-        VS("r480 8x6x10 t8 256 pf skew64", 0, 64, float, 480, 3, 8, 6, 10, 1, 8, 256, false, true, true, TW_LDS, 2, true),
-        VS("r480 8x6x10 t8 256 skew64", 0, 64, float, 480, 3, 8, 6, 10, 1, 8, 256, false, true, true, TW_LDS, 2, false),
         V("r480 8x6x10 t8 256 lds w2 pf", float, 480, 3, 8, 6, 10, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     };
 #elif GROUP == 6  // ---- config 5 y / x axes: columns of 128 ----
