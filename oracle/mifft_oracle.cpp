@@ -344,25 +344,28 @@ static inline Cx<T> load_x(const TIn* x, int64_t idx, int comps) {
     return {(T)x[2 * idx], (T)x[2 * idx + 1]};        // _fft.mojo:257
 }
 
-template <typename T, typename TIn>
-static void run_stage(const DimPlan<T>& dp, size_t b, Cx<T>* dst, const TIn* src, int comps,
-                      bool do_rfft, bool inverse) {
+// MODE: 0 large N (runtime twiddle table, plain complex FMA), 1 N <= 128 (strength-reduced phasors), 2 N <= 128 real
+// input.  COMPS and MODE are template parameters only so that the compiler can drop the per-element branches; the
+// arithmetic and its order are exactly those of the generic statement (the golden-vector tests pin them bit for bit).
+template <typename T, typename TIn, int COMPS, int MODE>
+static void run_stage_impl(const DimPlan<T>& dp, size_t b, Cx<T>* dst, const TIn* src, bool inverse) {
     const int64_t N = dp.N, R = (int64_t)dp.radices[b], P = (int64_t)dp.processed[b];
     const int64_t step = N / R;
     const bool last_inverse = inverse && P * R == N;
     const T inv_n = (T)(1.0 / (double)N);  // (1.0 / Float64(length)).cast[out_dtype]()
     const int32_t* sn = dp.src_n[b].data();
     const int32_t* ti = dp.tw_idx[b].data();
-    const uint8_t* kd = dp.small ? dp.kind[b].data() : nullptr;
+    const uint8_t* kd = MODE != 0 ? dp.kind[b].data() : nullptr;
+    const Cx<T>* tw = dp.tw.data();
     for (int64_t i = 0; i < N; ++i) {
         const int64_t n = sn[i];
-        Cx<T> acc = load_x<T, TIn>(src, n, comps);
+        Cx<T> acc = load_x<T, TIn>(src, n, COMPS);
         for (int64_t j = 1; j < R; ++j) {
-            Cx<T> xj = load_x<T, TIn>(src, n + j * step, comps);
-            Cx<T> w = dp.tw[ti[(j - 1) * N + i]];
-            if (!dp.small) {
+            Cx<T> xj = load_x<T, TIn>(src, n + j * step, COMPS);
+            Cx<T> w = tw[ti[(j - 1) * N + i]];
+            if (MODE == 0) {
                 acc = cfma(w, xj, acc);  // _fft.mojo:290
-            } else if (do_rfft) {
+            } else if (MODE == 2) {
                 acc = unit_phasor_fma_real(w, j == 1, xj.re, acc);  // _fft.mojo:382-383
             } else {
                 acc = unit_phasor_fma(kd[(j - 1) * N + i], w, xj, acc);  // _fft.mojo:385
@@ -373,6 +376,21 @@ static void run_stage(const DimPlan<T>& dp, size_t b, Cx<T>* dst, const TIn* src
             acc.im *= inv_n;
         }
         dst[i] = acc;
+    }
+}
+
+template <typename T, typename TIn>
+static void run_stage(const DimPlan<T>& dp, size_t b, Cx<T>* dst, const TIn* src, int comps,
+                      bool do_rfft, bool inverse) {
+    const int mode = !dp.small ? 0 : (do_rfft ? 2 : 1);
+    if (comps == 1) {
+        if (mode == 0) run_stage_impl<T, TIn, 1, 0>(dp, b, dst, src, inverse);
+        else if (mode == 1) run_stage_impl<T, TIn, 1, 1>(dp, b, dst, src, inverse);
+        else run_stage_impl<T, TIn, 1, 2>(dp, b, dst, src, inverse);
+    } else {
+        if (mode == 0) run_stage_impl<T, TIn, 2, 0>(dp, b, dst, src, inverse);
+        else if (mode == 1) run_stage_impl<T, TIn, 2, 1>(dp, b, dst, src, inverse);
+        else run_stage_impl<T, TIn, 2, 2>(dp, b, dst, src, inverse);
     }
 }
 
