@@ -528,6 +528,13 @@ int main(int argc, char** argv) {
         V("c128 8x4x4 t16 256 lds w4 pf", float, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, true),
         V("c128 32x4 t16 64 lds w4", float, 128, 2, 32, 4, 1, 1, 16, 64, true, true, true, TW_LDS, 4, false),
         V("c128 16x8 t16 128 reg w4", float, 128, 2, 16, 8, 1, 1, 16, 128, true, true, true, TW_REG, 4, false),
+        V("c128 16x8 t32 512 lds w4 pf", float, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 4, true),
+        V("c128 16x8 t32 512 lds w2 pf", float, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 2, true),
+        V("c128 8x16 t32 512 lds w4", float, 128, 2, 8, 16, 1, 1, 32, 512, true, true, true, TW_LDS, 4, false),
+        V("c128 8x16 t32 512 lds w4 pf", float, 128, 2, 8, 16, 1, 1, 32, 512, true, true, true, TW_LDS, 4, true),
+        V("c128 8x16 t64 512 lds w2 pf", float, 128, 2, 8, 16, 1, 1, 64, 512, true, true, true, TW_LDS, 2, true),
+        V("c128 16x8 t64 1024 lds w4", float, 128, 2, 16, 8, 1, 1, 64, 1024, true, true, true, TW_LDS, 4, false),
+        V("c128 4x4x8 t32 512 lds w4", float, 128, 3, 4, 4, 8, 1, 32, 512, true, true, true, TW_LDS, 4, false),
     };
 #elif GROUP == 19  // ---- config 3 again: radix 3 first (248-byte runs in pass 0), radix 31 last ----
     const long long batch = 500000, outer = 1, inner = 1;
