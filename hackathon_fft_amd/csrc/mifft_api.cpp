@@ -343,6 +343,7 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                 std::string whys;
                 ok = select_jit_streaming_rows(p, ps, whys);  // experiment switch, see kernels_jit.cpp
             }
+            if (!ok) ok = select_dpp_rows(p, ps);
             if (!ok) ok = select_fast(p, ps);
             // no table entry: specialise the tile kernel for this length now (strided dimensions up to 4096 points;
             // longer ones are better off on the transposed route below)

@@ -100,6 +100,8 @@ struct Plan {
 // accepts the (plan, pass) pair.
 bool select_generic(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_fast(const Plan& plan, DimPass& pass);
+// wave-autonomous rows of N = 3 * R0 points: radix R0 in registers, radix 3 across three lanes by DPP (kernels_dpp.hip)
+bool select_dpp_rows(const Plan& plan, DimPass& pass);
 // the tile kernel specialised at plan time with hipRTC for a length without a table entry (kernels_jit.cpp)
 bool select_jit(const Plan& plan, DimPass& pass, std::string& why_not);
 // four-step helpers: the transposed + twiddled column pass (reads x: real / integer input allowed) and cheap

@@ -701,7 +701,7 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < 16; ++k) ph[k] += (double)hs[g * 16 + k];
             printf("%-28s cycles per tile (thread 0):", vs[i].name.c_str());
             double tot = 0;
-            for (int k = 0; k < 14; ++k) {
+            for (int k = 0; k < 16; ++k) {
                 printf(" [%d]%6.0f", k, ph[k] / (double)g_last_tiles);
                 tot += ph[k] / (double)g_last_tiles;
             }
