@@ -199,4 +199,119 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel_dma_split(con
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// tile_kernel_pp<C>: PING-PONG column tiles.  A tile of a long strided dimension (16 columns x 640 points = 80 KB)
+// leaves room for ONE workgroup per CU, and a workgroup that does everything in lockstep adds up its load time, its
+// butterfly / LDS time and its store time (section "3.1b" of DESIGN.md).  Here the workgroup is two HALVES of
+// C::THREADS threads, each transforming its own tiles with the configuration C, shifted by half a tile period, and the
+// one LDS tile buffer changes hands between them:
+//
+//      half A:  | LDS phase: passes of tile 0        | memory phase: stores 0, loads 2      | LDS phase: tile 2 | ...
+//      half B:  | memory phase: loads 1              | LDS phase: passes of tile 1          | memory: stores 1, loads 3 | ...
+//
+// so one half's HBM traffic always runs beside the other half's butterflies and LDS exchanges.  A tile needs the buffer
+// from the scatter of pass 0 to the gather of the last pass; the last pass's butterflies and its HBM stores happen after
+// the buffer has been handed over, from registers.
+// Synchronisation is the workgroup barrier only.  Every PHASE has the same number of barriers for both halves
+// (1 + 2 NP - 3): the LDS half executes "acquire" and the barriers between its passes, the memory half executes
+// "release" (the same physical barrier as the other's acquire) and as many filler barriers.  Both halves run the same
+// number of phases (tiles beyond the end are processed as shadows: no HBM access, same barriers), so the barrier counts
+// match by construction and no wave can be left waiting.
+// Requirements: column tile, direct first and last pass, no prefetch / WSUB / TSTORE / cooperative primes.
+// MEASURED (tools/tune GROUP 22, 100 x 640 x 480 columns): 0.111 ms against 0.103 ms for the plain prefetching tile --
+// with only four waves in each phase (one per SIMD) the LDS instructions and the butterflies run far below their
+// rates (ds_*_b64 needs ~4 waves per SIMD), which costs more than the overlap brings.  Correct, not shipped.
+// ---------------------------------------------------------------------------------------------
+template <class C, int I>
+MIFFT_DEV void pp_lds_passes(const TileParams& p, cpx<typename C::T>* lds, cpx<typename C::T> (*cur)[C::R(0)],
+                             cpx<typename C::T> (*vlast)[C::R(C::NP - 1)], long long base, int nv, int htid) {
+    using V = cpx<typename C::T>;
+    const V* ltw = lds + C::DATA_ELEMS;
+    if constexpr (I == 0) {
+        V v[C::IPT(0)][C::R(0)];
+#pragma unroll
+        for (int k = 0; k < C::IPT(0); ++k)
+#pragma unroll
+            for (int j = 0; j < C::R(0); ++j) {
+                v[k][j] = cur[k][j];
+                if (p.inverse) v[k][j].y = -v[k][j].y;
+            }
+        pass_compute_scatter<C, 0>(p, lds, v, base, nv, htid);
+        wg_barrier<C>();
+        pp_lds_passes<C, 1>(p, lds, cur, vlast, base, nv, htid);
+    } else if constexpr (I < C::NP - 1) {
+        V v[C::IPT(I)][C::R(I)];
+        pass_gather_lds<C, I>(p, lds, ltw, nullptr, v, htid);
+        wg_barrier<C>();
+        pass_compute_scatter<C, I>(p, lds, v, base, nv, htid);
+        wg_barrier<C>();
+        pp_lds_passes<C, I + 1>(p, lds, cur, vlast, base, nv, htid);
+    } else {
+        pass_gather_lds<C, I>(p, lds, ltw, nullptr, vlast, htid);  // the buffer is released at the next barrier
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(2 * C::THREADS, 1) void tile_kernel_pp(const TileParams p) {
+    using T = typename C::T;
+    using V = cpx<T>;
+    static_assert(C::COLS && C::FIRST_DIRECT && C::LAST_DIRECT && !C::PREFETCH && !C::WSUB && !C::TSTORE && !C::FS1 &&
+                      !C::BIGP0 && C::TWMODE == TW_LDS && C::NP >= 2 && C::THREADS % 64 == 0,
+                  "ping-pong: a plain direct column tile with LDS twiddles");
+#ifdef MIFFT_STATIC_LDS
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
+#else
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
+    V* lds = (V*)smem;
+    constexpr int FILL = 2 * C::NP - 3;  // barriers between the passes of one LDS phase
+    const int half = threadIdx.x / C::THREADS;  // wave-uniform
+    const int htid0 = threadIdx.x - half * C::THREADS;
+    // twiddle table: filled by both halves together
+    for (int i = threadIdx.x; i < C::TWL_TOTAL; i += 2 * C::THREADS) lds[C::DATA_ELEMS + i] = V{(T)0, (T)0};
+    __syncthreads();
+    if (half == 0) fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, htid0, p.inverse);
+    __syncthreads();
+
+    // tiles of this workgroup: t_k = blockIdx.x + k * gridDim.x, k < cnt; half h takes k = h, h + 2, ...
+    const long long cnt = p.n_tiles > (long long)blockIdx.x ? (p.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const long long phases = 2 * ((cnt + 1) / 2);  // same for both halves
+    V cur[C::IPT(0)][C::R(0)];               // pass-0 inputs of the tile about to enter its LDS phase
+    V vlast[C::IPT(C::NP - 1)][C::R(C::NP - 1)];  // gathered inputs of the last pass of the tile that just left it
+    long long base_ld = 0, base_st = 0;
+    int nv_ld = 1, nv_st = 0;
+    auto geom = [&](long long k, long long& base, int& nv) {  // false: shadow tile (beyond the end)
+        if (k >= cnt) {
+            nv = 0;
+            return false;
+        }
+        tile_geom<C>(p, tile_id(p, (long long)blockIdx.x + k * gridDim.x), base, nv);
+        return true;
+    };
+    if (half == 0) {  // prologue: half A's first tile
+        if (geom(0, base_ld, nv_ld)) load_pass0<C>(p, cur, base_ld, nv_ld, htid0);
+    }
+    for (long long ph = 0; ph < phases; ++ph) {
+        int htid = htid0;
+        asm volatile("" : "+v"(htid));  // opaque per phase (see tile_kernel)
+        if ((ph & 1) == half) {
+            // ---- LDS phase of my tile k = ph (its loads were issued during my last memory phase / the prologue) ----
+            wg_barrier<C>();  // acquire: the other half has gathered its last pass
+            base_st = base_ld;
+            nv_st = nv_ld;
+            pp_lds_passes<C, 0>(p, lds, cur, vlast, base_st, nv_st, htid);
+        } else {
+            // ---- memory phase: finish my previous tile from registers, fetch my next one ----
+            wg_barrier<C>();  // release (pairs with the other half's acquire)
+            if (ph >= 1 && nv_st > 0) pass_compute_scatter<C, C::NP - 1>(p, lds, vlast, base_st, nv_st, htid);
+            if (geom(ph + 1, base_ld, nv_ld)) load_pass0<C>(p, cur, base_ld, nv_ld, htid);
+#pragma unroll
+            for (int f = 0; f < FILL; ++f) wg_barrier<C>();  // the other half's barriers between its passes
+        }
+    }
+    // the half that ran the last LDS phase (B: phases is even) releases and finishes its last tile
+    wg_barrier<C>();
+    if (half == 1 && phases > 0 && nv_st > 0) pass_compute_scatter<C, C::NP - 1>(p, lds, vlast, base_st, nv_st, threadIdx.x - C::THREADS);
+}
+
 }  // namespace mifft

@@ -86,6 +86,39 @@ Variant make(const char* name) {
     return v;
 }
 
+// ping-pong column tiles: two halves of C::THREADS threads share one LDS tile buffer (tile_kernel_pp)
+template <class C>
+Variant make_pp(const char* name) {
+    Variant v;
+    v.name = name;
+    v.lds = C::LDS_BYTES;
+    v.run = [](const void* in, void* out, const void* tw, long long batch, long long outer, long long inner) {
+        TileParams tp{};
+        tp.in = in;
+        tp.out = out;
+        tp.tw = tw;
+        tp.inverse = 0;
+        tp.scale = 1.0;
+        tp.inner = inner;
+        tp.tiles_per_outer = (inner + C::TILE - 1) / C::TILE;
+        tp.n_tiles = batch * outer * tp.tiles_per_outer;
+        auto k = tile_kernel_pp<C>;
+        static bool set = false;
+        if (!set && C::LDS_BYTES > 64 * 1024) {
+            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+            set = true;
+        }
+        long long per_cu = (160 * 1024) / (long long)C::LDS_BYTES;
+        if (per_cu > 1024 / C::THREADS) per_cu = 1024 / C::THREADS;
+        if (per_cu < 1) per_cu = 1;
+        if (g_wg_override > 0) per_cu = g_wg_override;
+        long long grid = std::min<long long>((long long)g_cus * per_cu, tp.n_tiles);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(2 * C::THREADS), C::LDS_BYTES, 0, tp);
+    };
+    return v;
+}
+#define VP(NAME, ...) make_pp<TileCfg<__VA_ARGS__>>(NAME)
+
 template <class C>
 Variant make_dma(const char* name) {
     Variant v;
@@ -584,6 +617,21 @@ int main(int argc, char** argv) {
         VW("c1024 16x4x4x4 t16 1024 wsub", float, 1024, 4, 16, 4, 4, 4, 16, 1024, true, true, true, TW_LDS, 1, false),
         VW("c1024 8x8x4x4 t16 512 wsub", float, 1024, 4, 8, 8, 4, 4, 16, 512, true, true, true, TW_LDS, 1, false),
         VW("c1024 8x4x4x8 t16 512 wsub", float, 1024, 4, 8, 4, 4, 8, 16, 512, true, true, true, TW_LDS, 1, false),
+    };
+#elif GROUP == 22  // ---- config 4 second pass: ping-pong halves sharing one LDS tile (tile_kernel_pp) ----
+    const long long batch = 100, outer = 1, inner = 480;
+    const int N = 640;
+    std::vector<Variant> vs = {
+        V("c640 10x8x8 t16 512 lds pf", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, true),
+        VW("c640 10x8x8 t16 640 wsub pf", float, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_LDS, 1, true),
+        VP("pp c640 10x8x8 t16 2x256", float, 640, 3, 10, 8, 8, 1, 16, 256, true, true, true, TW_LDS, 1, false),
+        VP("pp c640 10x8x8 t16 2x512", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_LDS, 1, false),
+        VP("pp c640 8x8x10 t16 2x256", float, 640, 3, 8, 8, 10, 1, 16, 256, true, true, true, TW_LDS, 1, false),
+        VP("pp c640 4x4x8x5 t16 2x256", float, 640, 4, 4, 4, 8, 5, 16, 256, true, true, true, TW_LDS, 1, false),
+        VP("pp c640 4x4x8x5 t16 2x512", float, 640, 4, 4, 4, 8, 5, 16, 512, true, true, true, TW_LDS, 1, false),
+        VP("pp c640 20x32 t16 2x256", float, 640, 2, 20, 32, 1, 1, 16, 256, true, true, true, TW_LDS, 1, false),
+        VP("pp c640 16x8x5 t16 2x256", float, 640, 3, 16, 8, 5, 1, 16, 256, true, true, true, TW_LDS, 1, false),
+        VP("pp c640 10x8x8 t16 2x320", float, 640, 3, 10, 8, 8, 1, 16, 320, true, true, true, TW_LDS, 1, false),
     };
 #else
 #error "define GROUP"
