@@ -21,7 +21,9 @@ The default run also carries the strong-scaling leg as the object `strong_config
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline       HBM roofline of the dominant kernel; `achieved` = algorithmic bytes per launch (16 B per complex element:
                  one 8-B read + one 8-B write) / the average launch duration measured with HIP events on
-                 the launch stream inside libmifft (mifft_time_exec)
+                 the launch stream inside libmifft (mifft_time_exec); `traffic` = HBM bytes per step from `rocprofv3
+                 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` child passes of this command, run by this process BEFORE it
+                 touches the GPU (N=1 default run; else the committed profile of the same command)
   ramp           the untimed clock / cache ramp that precedes the W warm-up steps (ms, execs)
   configs        (N=1) the other four BASELINE.json configs, each timed the same way in this run
   cpu_baseline   (N=1) the CPU oracle (restatement of the reference's multi-threaded CPU path) on this host's cores on a
@@ -211,6 +213,55 @@ def vendor_compare(timeout_s=240):
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# live HBM-traffic counters: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS command
+# ------------------------------------------------------------------------------------------------
+FETCH_FACTOR = 2.0  # gfx950 counts the 8- / 16-byte-per-lane streaming reads of these kernels at 1/2 (guide, "HBM";
+                    # calibrated 1.99993-2.00000 on a known-bytes copy of the same access shape in every profiles/rNN_*)
+
+
+def live_pmc_traffic(workload, timeout_s=150):
+    """{kernel name fragment: bytes per launch} measured NOW: two child runs of this script under rocprofv3 (one counter
+    per pass: FETCH_SIZE and WRITE_SIZE do not fit one pass), started before this process has touched the GPU.  The
+    program after `--` is python3 itself (no shell, no env hop).  None when rocprofv3 is missing or a pass fails -- the
+    caller then falls back to the committed profile."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="mifft_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--workload", workload, "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                   "--no-configs", "--no-strong-leg", "--no-compare-vendor", "--no-live-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode:
+                return None
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and "mifft::" in row["Kernel_Name"]:
+                        acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not acc:
+                return None
+            for k, v in acc.items():
+                kib = sum(v) / len(v)
+                res.setdefault(k, {})[counter] = kib * 1024.0 * (FETCH_FACTOR if counter == "FETCH_SIZE" else 1.0)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {k: v["FETCH_SIZE"] + v["WRITE_SIZE"] for k, v in res.items() if len(v) == 2}
+    return out or None
+
+
 def _claim_stdout():
     """Keep stdout clean for the ONE JSON line: native libraries (RCCL prints a version banner on
     init) write to fd 1 directly, so fd 1 is pointed at stderr and the JSON goes to the saved fd."""
@@ -233,6 +284,9 @@ def parse_args(argv=None):
     ap.add_argument("--compare-vendor", dest="vendor", action="store_true", default=None,
                     help="rocFFT comparator column (default: on at N=1 when tools/vendor_fft_bench exists)")
     ap.add_argument("--no-compare-vendor", dest="vendor", action="store_false")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect roofline.traffic with rocprofv3 child runs (N=1, headline workload only); the "
+                         "committed profile is used instead")
     ap.add_argument("--faithful", action="store_true", help="force the literal stage-per-pass kernel family")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="arithmetic type (BASELINE metric: f32)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -380,6 +434,12 @@ class Bench:
         achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
         kernels = [plan.kernel_name(d) for d in range(len(shape) - 1)]
         traffic = measured_traffic(name, kernels)
+        live = getattr(self, "live_traffic", {}).get(name)
+        if live and len(live) == len(set(kernels)):
+            # measured in THIS run: sum over the kernels of one step (one entry per distinct kernel)
+            traffic = (sum(live.values()),
+                       "live rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command in this run "
+                       f"(FETCH_SIZE x {FETCH_FACTOR}, guide 'HBM'); committed: " + (traffic[1] if traffic else "none"), "")
         return {
             "workload": name, "baseline_config_index": cfg_idx, "shape": list(shape) + [2],
             "ms_per_step": round(ms_per_step, 5),
@@ -392,7 +452,8 @@ class Bench:
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic[0] if traffic else None,
-                "traffic_source": (traffic[1] + " (committed rocprofv3 --pmc passes of this command)") if traffic else None,
+                "traffic_source": (traffic[1] if traffic[1].startswith("live") else
+                                   traffic[1] + " (committed rocprofv3 --pmc passes of this command)") if traffic else None,
                 "kernel": "+".join(kernels), "algorithmic_bytes_per_launch": algo_bytes,
                 "launch_ms_hip_events": round(launch_ms, 5),
             },
@@ -440,8 +501,9 @@ class Bench:
         }
 
 
-def worker(args, json_out):
+def worker(args, json_out, live_traffic=None):
     b = Bench(args)
+    b.live_traffic = live_traffic or {}
     mf = b.mf
     strong = args.scaling == "strong"
     name = args.workload or (STRONG_WORKLOAD if strong else DEFAULT_WORKLOAD)
@@ -540,7 +602,16 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, json_out))  # nothing in this process has touched torch or the GPU
-    worker(args, json_out)
+    live = {}
+    headline = (args.workload or DEFAULT_WORKLOAD) == DEFAULT_WORKLOAD and args.scaling == "weak"
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and headline and not args.no_live_pmc and
+            args.dtype == "f32" and not args.faithful):
+        # child processes under rocprofv3; this process has not touched the GPU yet
+        for w in [DEFAULT_WORKLOAD] + ([] if args.no_configs else OTHER_BASELINE_CONFIGS):
+            t = live_pmc_traffic(w)
+            if t:
+                live[w] = t
+    worker(args, json_out, live)
 
 
 if __name__ == "__main__":

@@ -91,6 +91,9 @@ def test_bench_single_gpu_line_carries_every_baseline_config():
     assert r.returncode == 0, r.stderr[-4000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["roofline"]["bound"] == "hbm" and d["ramp"]["execs"] > 0
+    # HBM traffic from PMC counters collected by this very run (rocprofv3 child passes), within 1 % of the algorithmic bytes
+    assert d["roofline"]["traffic_source"].startswith("live")
+    assert abs(d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"] - 1.0) < 0.01
     assert [c["baseline_config_index"] for c in d["configs"]] == [0, 2, 3, 4]
     for c in d["configs"]:
         assert 0 < c["roofline"]["frac"] < 1 and c["ms_per_step"] > 0 and c["kernels"]
