@@ -220,7 +220,7 @@ FETCH_FACTOR = 2.0  # gfx950 counts the 8- / 16-byte-per-lane streaming reads of
                     # calibrated 1.99993-2.00000 on a known-bytes copy of the same access shape in every profiles/rNN_*)
 
 
-def live_pmc_traffic(workload, timeout_s=150):
+def live_pmc_traffic(workload, timeout_s=60):
     """{kernel name fragment: bytes per launch} measured NOW: two child runs of this script under rocprofv3 (one counter
     per pass: FETCH_SIZE and WRITE_SIZE do not fit one pass), started before this process has touched the GPU.  The
     program after `--` is python3 itself (no shell, no env hop).  None when rocprofv3 is missing or a pass fails -- the
@@ -606,11 +606,17 @@ def main():
     headline = (args.workload or DEFAULT_WORKLOAD) == DEFAULT_WORKLOAD and args.scaling == "weak"
     if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and headline and not args.no_live_pmc and
             args.dtype == "f32" and not args.faithful):
-        # child processes under rocprofv3; this process has not touched the GPU yet
+        # child processes under rocprofv3; this process has not touched the GPU yet.  Bounded: one failed or slow pass
+        # ends the collection (the committed profiles are the fallback), and the whole of it gets at most 2 minutes
+        t_live = time.perf_counter()
         for w in [DEFAULT_WORKLOAD] + ([] if args.no_configs else OTHER_BASELINE_CONFIGS):
-            t = live_pmc_traffic(w)
-            if t:
-                live[w] = t
+            left = 120.0 - (time.perf_counter() - t_live)
+            if left < 10.0:
+                break
+            t = live_pmc_traffic(w, timeout_s=min(60.0, left))
+            if not t:
+                break
+            live[w] = t
     worker(args, json_out, live)
 
 
