@@ -418,9 +418,12 @@ MIFFT_DEV void fill_lds_tw(cpx<typename C::T>* ltw, const cpx<typename C::T>* tw
 // (the tuner launches with 256 extra bytes) and copies them to the buffer passed in TileParams::tcol at the end
 // ([workgroup][16] shader cycles); stamp values never reach an output element.
 #ifdef MIFFT_STAMPS
+#ifndef MIFFT_STAMP_TID
+#define MIFFT_STAMP_TID 0  // the stamping thread (its wave is the one measured)
+#endif
 MIFFT_DEV void mifft_stamp(int i, unsigned lds_off, const void* dump = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_stamp[];  // the kernel's dynamic LDS
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == MIFFT_STAMP_TID) {
         unsigned long long* a = (unsigned long long*)(smem_stamp + ((lds_off + 15) / 16) * 16);
         const unsigned long long t = __builtin_amdgcn_s_memtime();
         if (i < 0) {
@@ -1232,8 +1235,11 @@ MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long
             }
         }
         if constexpr (I == CC::NP - 1) {
+            MIFFT_STAMP(G, 4);  // column passes up to the last gather
             __syncthreads();  // last LDS read of this plane: the next plane's row passes may overwrite the buffer
+            MIFFT_STAMP(G, 5);  // barrier behind the last gather
             before_stores();  // wait for the prefetched plane ahead of the HBM stores (run_pass)
+            MIFFT_STAMP(G, 6);  // drain: wait for the prefetched plane
         } else {
             wave_lds_fence();
         }
@@ -1287,6 +1293,7 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const T
     __syncthreads();
 
     constexpr long long PLANE = (long long)G::N1 * G::N2;
+    MIFFT_STAMP(G, -1);
     V pre[G::RIPT(0)][CR::R(0)];
     long long t = blockIdx.x;
     if (t < p.n_tiles) wp_load_rows<CR, CC, PAD>(p, pre, tile_id(p, t) * PLANE, tid0 >> 6, tid0 & 63);
@@ -1317,12 +1324,17 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const T
         auto drain = [&]() {  // ahead of this plane's HBM stores (tile_kernel / run_pass)
             if constexpr (CR::PREFETCH) vm_drain();
         };
+        MIFFT_STAMP(G, 0);  // plane bookkeeping, take-over of the prefetched registers, first slice of the next loads
         wp_row_passes<CR, CC, PAD, 0>(p, lds, cur, wave, lane, slice);
+        MIFFT_STAMP(G, 1);  // row passes (wave-private)
         __syncthreads();  // hand-over: every row is complete before any column starts
+        MIFFT_STAMP(G, 2);  // hand-over barrier
         slice(IntC<2>{});
         wp_col_passes<CR, CC, PAD, 0>(p, lds, base, wave, lane, drain, slice);
+        MIFFT_STAMP(G, 3);  // column passes incl. the barrier behind the last gather and the HBM stores
         if (!CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD>(p, pre, tile_id(p, tn) * PLANE, wave, lane);
     }
+    MIFFT_STAMP_DUMP(G, p);
 }
 
 // ---------------------------------------------------------------------------------------------

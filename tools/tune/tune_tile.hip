@@ -219,7 +219,17 @@ Variant make_plane_wp(const char* name) {
         if (per_cu < 1) per_cu = 1;
         if (g_wg_override > 0) per_cu = g_wg_override;
         long long grid = std::min<long long>(g_cus * per_cu, tp.n_tiles);
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(CR::THREADS), G::LDS_BYTES, 0, tp);
+#ifdef MIFFT_STAMPS
+        tp.tcol = g_stamps;
+        g_last_grid = grid;
+        g_last_tiles = tp.n_tiles;
+        static bool set2 = false;
+        if (!set2) {
+            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES + STAMP_LDS));
+            set2 = true;
+        }
+#endif
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(CR::THREADS), G::LDS_BYTES + STAMP_LDS, 0, tp);
     };
     return v;
 }
