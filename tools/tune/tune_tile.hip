@@ -352,6 +352,17 @@ int main(int argc, char** argv) {
         V("r480 4x4x30 t8 256 lds w2", float, 480, 3, 4, 4, 30, 1, 8, 256, false, true, true, TW_LDS, 2, false),
         V("r480 10x6x8 t8 256 lds w2 pf", float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
         V("r480 8x6x10 t8 256 lds w2 pf", float, 480, 3, 8, 6, 10, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+        VN("r480 10x6x8 t8 256 pf nt1", 1, float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+        VN("r480 4x4x5x6 t8 512 w2 nt1", 1, float, 480, 4, 4, 4, 5, 6, 8, 512, false, true, true, TW_LDS, 2, false),
+        VN("r480 5x4x4x6 t8 512 w2 nt1", 1, float, 480, 4, 5, 4, 4, 6, 8, 512, false, true, true, TW_LDS, 2, false),
+        VN("r480 6x5x4x4 t8 512 w2 nt1", 1, float, 480, 4, 6, 5, 4, 4, 8, 512, false, true, true, TW_LDS, 2, false),
+        VN("r480 4x5x4x6 t8 512 w2 nt1", 1, float, 480, 4, 4, 5, 4, 6, 8, 512, false, true, true, TW_LDS, 2, false),
+        VN("r480 4x4x5x6 t16 1024 w4 nt1", 1, float, 480, 4, 4, 4, 5, 6, 16, 1024, false, true, true, TW_LDS, 4, false),
+        VN("r480 4x4x5x6 t4 256 w2 nt1", 1, float, 480, 4, 4, 4, 5, 6, 4, 256, false, true, true, TW_LDS, 2, false),
+        VN("r480 8x6x10 t8 512 w2 nt1", 1, float, 480, 3, 8, 6, 10, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+        VN("r480 10x6x8 t8 384 w2 nt1", 1, float, 480, 3, 10, 6, 8, 1, 8, 384, false, true, true, TW_LDS, 2, false),
+        VN("r480 10x6x8 t16 512 w2 nt1", 1, float, 480, 3, 10, 6, 8, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+        VN("r480 6x8x10 t8 512 w2 nt1", 1, float, 480, 3, 6, 8, 10, 1, 8, 512, false, true, true, TW_LDS, 2, false),
     };
 #elif GROUP == 6  // ---- config 5 y / x axes: columns of 128 ----
     const long long batch = 10, outer = 128, inner = 128;  // y axis; x axis is outer 1, inner 16384
