@@ -10,7 +10,12 @@
 // conj(F(conj x)), which is bit-identical to running with conjugated twiddles.
 #pragma once
 
+// hipRTC (runtime specialisation, kernels_jit.cpp) brings the HIP device declarations itself; asking it for the header
+// file makes the build depend on an include path that is not always there (under rocprofv3 it is not: the include
+// failed and every runtime-specialised plan silently fell back to the literal-stage kernels)
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 // Results must not depend on which tile slot / unrolled code instance a transform lands in (a slab of
 // the batch must equal the same rows of the whole batch bit for bit, also across GPUs), so the compiler

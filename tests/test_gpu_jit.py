@@ -1,6 +1,7 @@
 """Runtime-specialised tile kernels (hackathon_fft_amd/csrc/kernels_jit.cpp): lengths without a precompiled table
 entry get the same fused kernel template, compiled with hipRTC at plan creation.  Checked against the oracle (small
 lengths) and fp64 pocketfft, contiguous and strided, fp32 / fp64, real input, inverse round trips, ragged batches."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -266,3 +267,35 @@ def test_l2_resident_image_kernel_opt_in(shape, monkeypatch):
     assert np.array_equal(again, out)          # barrier counters are reset per launch; results are reproducible
     back, _ = _run(out, inverse=True)
     assert rel_l2(back, x) < REL_L2_TOL_F32
+
+
+_UNDER_PROFILER = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+import hackathon_fft_amd as mf
+for shape in [(8, 343), (1, 7680, 64)]:
+    full = tuple(shape) + (2,)
+    plan = mf.plan_fft(torch.float32, torch.float32, full, full, ctx=mf.DeviceContext(0))
+    print("KERNELS", shape, [plan.kernel_name(d) for d in range(len(shape) - 1)])
+"""
+
+
+def test_runtime_specialisation_also_works_under_the_profiler(tmp_path):
+    # hipRTC has no <hip/hip_runtime.h> on its search path inside a rocprofv3 run: the shared headers must not ask for it,
+    # or every specialised plan silently degrades to the literal-stage kernels exactly when it is being measured
+    import shutil
+    import subprocess
+    import sys
+    from conftest import ROOT
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        pytest.skip("rocprofv3 not on PATH")
+    script = tmp_path / "plans.py"
+    script.write_text(_UNDER_PROFILER % {"root": ROOT})
+    env = dict(os.environ, TMPDIR=str(tmp_path), MIFFT_JIT_VERBOSE="1")
+    r = subprocess.run([prof, "--kernel-trace", "-d", str(tmp_path / "prof"), "--", sys.executable, str(script)],
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = r.stdout + r.stderr
+    assert "KERNELS (8, 343) ['rows343_7x7x7_jit']" in out, out[-3000:]
+    assert "_fs1_jit" in out and "runtime specialisation of" not in out, out[-3000:]
