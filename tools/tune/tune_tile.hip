@@ -654,6 +654,21 @@ int main(int argc, char** argv) {
         VP("pp c640 16x8x5 t16 2x256", float, 640, 3, 16, 8, 5, 1, 16, 256, true, true, true, TW_LDS, 1, false),
         VP("pp c640 10x8x8 t16 2x320", float, 640, 3, 10, 8, 8, 1, 16, 320, true, true, true, TW_LDS, 1, false),
     };
+#elif GROUP == 23  // ---- 8K frame rows: 4320 x 7680 (fewer, larger passes?) ----
+    const long long batch = 4320, outer = 1, inner = 1;
+    const int N = 7680;
+    std::vector<Variant> vs = {
+        V("r7680 12x10x8x8 1024 lds pf", float, 7680, 4, 12, 10, 8, 8, 1, 1024, false, true, true, TW_LDS, 1, true),
+        V("r7680 12x10x8x8 512 lds w2", float, 7680, 4, 12, 10, 8, 8, 1, 512, false, true, true, TW_LDS, 2, false),
+        V("r7680 12x10x8x8 512 lds w2 pf", float, 7680, 4, 12, 10, 8, 8, 1, 512, false, true, true, TW_LDS, 2, true),
+        V("r7680 20x24x16 512 lds w2", float, 7680, 3, 20, 24, 16, 1, 1, 512, false, true, true, TW_LDS, 2, false),
+        V("r7680 20x24x16 512 lds w2 pf", float, 7680, 3, 20, 24, 16, 1, 1, 512, false, true, true, TW_LDS, 2, true),
+        V("r7680 16x20x24 512 lds w2", float, 7680, 3, 16, 20, 24, 1, 1, 512, false, true, true, TW_LDS, 2, false),
+        V("r7680 24x20x16 512 glb w2", float, 7680, 3, 24, 20, 16, 1, 1, 512, false, true, true, TW_GLOBAL, 2, false),
+        V("r7680 16x16x30 512 lds w2", float, 7680, 3, 16, 16, 30, 1, 1, 512, false, true, true, TW_LDS, 2, false),
+        V("r7680 32x16x15 512 lds w2", float, 7680, 3, 32, 16, 15, 1, 1, 512, false, true, true, TW_LDS, 2, false),
+        V("r7680 12x10x8x8 1024 glb w1 pf", float, 7680, 4, 12, 10, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 1, true),
+    };
 #else
 #error "define GROUP"
 #endif
