@@ -95,6 +95,11 @@ struct FastEntry {
     MIFFT_CFG_X(false, false, 0, -1, NAME, __VA_ARGS__), MIFFT_CFG_X(false, true, 0, -1, NAME "_r", __VA_ARGS__)
 // non-temporal twin for problems that dwarf the Infinity Cache (listed BEFORE the plain entry)
 #define MIFFT_CFG_STREAM(NAME, ...) MIFFT_CFG_X(false, false, 3, 1, NAME "_nt", __VA_ARGS__)
+// ... for real input (the reference's own benchmark is the real-input one, fft/bench.mojo:57-97): 0.2407 -> 0.2326 ms at
+// 100k x 1024, against 0.2095 ms for a promoting copy of the same bytes (tools/micro/rw_mix.hip)
+#define MIFFT_CFG_STREAM_R(NAME, ...) MIFFT_CFG_X(false, true, 3, 1, NAME "_r_nt", __VA_ARGS__)
+#define MIFFT_CFG_STREAM_ST_R(NAME, ...) MIFFT_CFG_X(false, true, 2, 1, NAME "_r_nts", __VA_ARGS__)
+#define MIFFT_CFG_NTL_R(NAME, ...) MIFFT_CFG_X(false, true, 1, 2, NAME "_r_ntl", __VA_ARGS__)
 // ... with non-temporal stores only (tiles staged through a flat LDS copy re-read their lines)
 #define MIFFT_CFG_STREAM_ST(NAME, ...) MIFFT_CFG_X(false, false, 2, 1, NAME "_nts", __VA_ARGS__)
 // ... with non-temporal loads only: first pass of an N-D transform whose `out` fits the Infinity Cache

@@ -13,26 +13,35 @@ static const FastEntry kFastTable[] = {
     // the 256-VGPR edge: a refactor that added 20 B of scratch doubled their time.)
     // streaming twin: four small-radix passes, 512 threads x 8 elements (low VGPR count, 32 waves/CU): 0.274 ms
     MIFFT_CFG_STREAM("rows1024_4x4x8x8", float, MIFFT_F32, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_STREAM_R("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
     MIFFT_CFG_CR("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
     // power-of-two rows (tools/tune GROUP 9-12, 819-MB tensors): plain 0.304-0.316 ms, streaming twins 0.277-0.295 ms
     MIFFT_CFG_STREAM("rows512_4x4x4x8", float, MIFFT_F32, 512, 4, 4, 4, 4, 8, 8, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_STREAM_R("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM("rows256_8x8x4", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_STREAM_R("rows256_8x8x4", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows256_8x8x4", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
+    MIFFT_CFG_STREAM_R("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_CR("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_CR("rows64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_STREAM("rows2048_4x8x8x8", float, MIFFT_F32, 2048, 4, 4, 8, 8, 8, 2, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_STREAM_R("rows2048_16x16x8", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows2048_16x16x8", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM("rows4096_8x8x8x8", float, MIFFT_F32, 4096, 4, 8, 8, 8, 8, 1, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_STREAM_R("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
     // one 128-KiB row per workgroup; twiddles from the global table (the compact LDS table would need 131 KB more)
     MIFFT_CFG("rows16384_16x16x8x8", float, MIFFT_F32, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, false),
     MIFFT_CFG_STREAM_ST("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+    MIFFT_CFG_STREAM_ST_R("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
     MIFFT_CFG_CR("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
     MIFFT_CFG_NTL("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_NTL("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_NTL_R("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_CR("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_NTL_R("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_CR("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     // ---- strided dimensions, fp32 (in place, LDS column tiles) ----
     // ten waves, one per sub-problem of the radix-10 first pass (WSUB): the 8 x 8 passes exchange without workgroup
@@ -148,7 +157,8 @@ static int prepare_plane() {
 }
 
 struct PlaneEntry {
-    bool ntl;  // non-temporal loads of x: first pass of a cache-resident N-D transform
+    bool ntl;      // non-temporal loads of x: first pass of a cache-resident N-D transform
+    bool in_real;  // reads a real (C_in = 1) tensor
     int out_dtype;
     int N1, N2;
     const char* name;
@@ -172,24 +182,32 @@ using Plane128C = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, true, false, tr
 using Plane128WR = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true>;
 using Plane128WC = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false>;
 using Plane64RN = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false, 0, false, false, 1>;
+// real-input twins (C_in = 1 promoted in the pass-0 load)
+using Plane64RR = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false, 0, true>;
+using Plane128WRR = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true, 0, true>;
 // (a non-temporal twin of the 128 x 128 plane measured SLOWER: 75.5 -> 80.5 us for 1280 planes; its next-plane
 //  register prefetch already keeps the loads far ahead)
 
 static const PlaneEntry kPlaneTable[] = {
-    {true, MIFFT_F32, 64, 64, "plane64x64_8x8_ntl", launch_plane<Plane64RN, Plane64C>,
+    {true, false, MIFFT_F32, 64, 64, "plane64x64_8x8_ntl", launch_plane<Plane64RN, Plane64C>,
      prepare_plane<Plane64RN, Plane64C>, 512, Plane64RN::LDS_BYTES},
-    {false, MIFFT_F32, 64, 64, "plane64x64_8x8", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>,
+    {false, false, MIFFT_F32, 64, 64, "plane64x64_8x8", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>,
      512, Plane64R::LDS_BYTES},
+    {false, true, MIFFT_F32, 64, 64, "plane64x64_8x8_r", launch_plane<Plane64RR, Plane64C>, prepare_plane<Plane64RR, Plane64C>,
+     512, Plane64RR::LDS_BYTES},
     // wave-private exchanges (plane_kernel_wp): 2 workgroup barriers per plane instead of 12; 1280 planes 0.0812 ->
     // 0.0744 ms (tools/tune GROUP 7).  For 64 x 64 planes (four workgroups per CU already overlap) it ties.
-    {false, MIFFT_F32, 128, 128, "plane128x128_8x16_wp", launch_plane_wp<Plane128WR, Plane128WC, 8>,
+    {false, false, MIFFT_F32, 128, 128, "plane128x128_8x16_wp", launch_plane_wp<Plane128WR, Plane128WC, 8>,
      prepare_plane_wp<Plane128WR, Plane128WC, 8>, 1024, WavePlane<Plane128WR, Plane128WC, 8>::LDS_BYTES},
+    {false, true, MIFFT_F32, 128, 128, "plane128x128_8x16_wp_r", launch_plane_wp<Plane128WRR, Plane128WC, 8>,
+     prepare_plane_wp<Plane128WRR, Plane128WC, 8>, 1024, WavePlane<Plane128WRR, Plane128WC, 8>::LDS_BYTES},
 };
 
 bool select_fast_plane(const Plan& plan, DimPass& pass) {
-    if (plan.in_dtype != plan.out_dtype || plan.in_components != 2) return false;
+    if (plan.in_dtype != plan.out_dtype) return false;
     for (const PlaneEntry& e : kPlaneTable) {
         if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
+        if (e.in_real != (pass.first && plan.in_components == 1)) continue;
         if (e.ntl && !(plan.cache_resident_nd && plan.ndim > 2)) continue;  // a 2-D plane is the only pass: nothing to keep
         pass.kernel_name = e.name;
         pass.launch = e.launch;

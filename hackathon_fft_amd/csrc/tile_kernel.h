@@ -1150,6 +1150,7 @@ template <class CR, class CC, int PAD, int PART = 0, int NPARTS = 1>
 MIFFT_DEV void wp_load_rows(const TileParams& p, cpx<typename CR::T> (*v)[CR::R(0)], long long base, int wave, int lane) {
     using G = WavePlane<CR, CC, PAD>;
     using V = cpx<typename CR::T>;
+    using T = typename CR::T;
     constexpr int R = CR::R(0), NB = CR::NB(0), IPT = G::RIPT(0);
     const V* gin = (const V*)p.in;
 #pragma unroll
@@ -1157,8 +1158,17 @@ MIFFT_DEV void wp_load_rows(const TileParams& p, cpx<typename CR::T> (*v)[CR::R(
         const int sub = k * 64 + lane, rl = sub / NB, b = sub - rl * NB;
         const unsigned off = (unsigned)(wave * G::RPW + rl) * (unsigned)G::N2 + (unsigned)b;
 #pragma unroll
-        for (int j = 0; j < R; ++j)
-            if ((k * R + j) % NPARTS == PART) v[k][j] = gload<(CR::NT & 1) != 0>(gin + base + j * NB + off);
+        for (int j = 0; j < R; ++j) {
+            if ((k * R + j) % NPARTS != PART) continue;  // (compile-time after unrolling)
+            if constexpr (!same_t<typename CR::IT, T>::value) {
+                v[k][j] = load_foreign<CR>(p.in, base + j * NB + off);
+            } else if constexpr (CR::IN_REAL) {  // real tensor promoted in the load (load_pass0)
+                v[k][j].x = gload_real<(CR::NT & 1) != 0>((const T*)p.in + base + j * NB + off);
+                v[k][j].y = (T)0;
+            } else {
+                v[k][j] = gload<(CR::NT & 1) != 0>(gin + base + j * NB + off);
+            }
+        }
     }
 }
 
@@ -1279,7 +1289,6 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const T
     static_assert(!CR::COLS && CC::COLS && CR::N == CC::TILE && CR::TILE == CC::N, "plane geometry");
     static_assert(CR::THREADS == CC::THREADS && CR::TWMODE == TW_LDS && CC::TWMODE == TW_LDS, "one thread count, LDS twiddles");
     static_assert(G::exact(), "every pass must be an exact number of wave rounds over wave-owned rows / columns");
-    static_assert(same_t<typename CR::IT, T>::value && !CR::IN_REAL, "complex input of the plan's dtype");
     static_assert(G::LDS_BYTES <= 160 * 1024, "plane + twiddle tables must fit LDS");
 #ifdef MIFFT_STATIC_LDS
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];

@@ -335,6 +335,48 @@ def test_full_size_properties(shape, bases):
     assert ((lhs - rhs).reshape(k, -1).norm(dim=1) / rhs.reshape(k, -1).norm(dim=1)).max().item() < 1e-5
 
 
+# the reference's own benchmark is the real-input one (bench_gpu_radix_n_rfft, fft/bench.mojo:57-97,108-124): its shapes
+REAL_FULL_SIZES = [(250000, 93), (250000, 128), (100000, 1024), (100, 640, 480), (100, 64, 64, 64), (10, 128, 128, 128)]
+
+
+@pytest.mark.parametrize("shape", REAL_FULL_SIZES)
+def test_full_size_real_input(shape):
+    """C_in = 1 at the reference's benchmark sizes (streaming `_r_nt` twins, real-input planes): equal to the complex
+    plan on (x, 0) within rounding, Hermitian-symmetric, and oracle spot-checks incl. the ragged last tile."""
+    g = torch.Generator(device=DEV).manual_seed(4321)
+    x = torch.randn(shape + (1,), generator=g, device=DEV, dtype=torch.float32)
+    out = torch.full(shape + (2,), float("nan"), device=DEV)
+    ctx = mf.DeviceContext(0)
+    plan = mf.plan_fft(torch.float32, torch.float32, x.shape, out.shape, ctx=ctx)
+    mf.fft(out, x, ctx, plan=plan)
+    ctx.synchronize()
+    assert not torch.isnan(out).any()
+    assert "generic" not in [plan.kernel_name(d) for d in range(len(shape) - 1)]
+    xc = torch.cat([x, torch.zeros_like(x)], dim=-1).contiguous()
+    outc = torch.empty_like(out)
+    cplan = mf.plan_fft(torch.float32, torch.float32, xc.shape, out.shape, ctx=ctx)
+    mf.fft(outc, xc, ctx, plan=cplan)
+    ctx.synchronize()
+    b = shape[0]
+    num = (out.double() - outc.double()).reshape(b, -1).norm(dim=1)
+    den = outc.double().reshape(b, -1).norm(dim=1)
+    assert (num / den).max().item() < 2e-6
+    # Hermitian symmetry X[-k] = conj(X[k]) on a slab of the batch (index reversal along every transformed dimension)
+    k = min(b, 16)
+    z = torch.view_as_complex(out[:k].contiguous())
+    dims = tuple(range(1, z.dim()))
+    zr = torch.roll(torch.flip(z, dims), shifts=[1] * len(dims), dims=dims)
+    assert ((zr.conj() - z).abs().reshape(k, -1).norm(dim=1) / z.abs().reshape(k, -1).norm(dim=1)).max().item() < 2e-6
+    step = max(1, b // 6)
+    idx = sorted({0, b - 1} | set(range(0, b, step)) | {((b - 1) // 64) * 64})
+    sel = torch.tensor(idx, device=DEV)
+    xs = x.index_select(0, sel).cpu().numpy()
+    ref = O.fftn(xs)
+    got = out.index_select(0, sel).cpu().numpy()
+    for i in range(len(idx)):
+        assert rel_l2(got[i:i + 1], ref[i:i + 1]) < REL_L2_TOL_F32, (shape, idx[i])
+
+
 @pytest.mark.parametrize("n,batch,dtype", [(32768, 3, np.float32), (65536, 2, np.float32), (1 << 20, 1, np.float32),
                                            (100000, 3, np.float32), (98304, 2, np.float32), (20480, 5, np.float32),
                                            (50000, 2, np.float64), (1 << 17, 1, np.float64), (1 << 22, 1, np.float32),

@@ -239,6 +239,8 @@ Variant make_plane_wp(const char* name) {
 #define VW(NAME, ...) make<TileCfg<__VA_ARGS__, 0, false, false, 0, false, float, true>>(NAME)
 // explicit non-temporal mode: ... PF, then NT (0 none, 1 loads, 2 stores, 3 both)
 #define VN(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, false, false, NT>>(NAME)
+// real input (C_in = 1) promoted in the pass-0 load: ... PF, then NT
+#define VR(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, true, false, NT>>(NAME)
 // ... with an LDS row pad (ROWS: pitch = N + PAD)
 #define VNP(NAME, NT, PAD, ...) make<TileCfg<__VA_ARGS__, PAD, false, false, NT>>(NAME)
 // DMA-staged flat-copy rows: T N NP R0..R3 TILE THREADS TWMODE MINW
@@ -668,6 +670,20 @@ int main(int argc, char** argv) {
         V("r7680 16x16x30 512 lds w2", float, 7680, 3, 16, 16, 30, 1, 1, 512, false, true, true, TW_LDS, 2, false),
         V("r7680 32x16x15 512 lds w2", float, 7680, 3, 32, 16, 15, 1, 1, 512, false, true, true, TW_LDS, 2, false),
         V("r7680 12x10x8x8 1024 glb w1 pf", float, 7680, 4, 12, 10, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 1, true),
+    };
+#elif GROUP == 24  // ---- real input (the reference benchmarks rfft): 100k x 1024 real -> complex ----
+    const long long batch = 100000, outer = 1, inner = 1;
+    const int N = 1024;
+    std::vector<Variant> vs = {
+        VR("r 16x8x8 t4 256 lds w4 nt0", 0, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VR("r 16x8x8 t4 256 lds w4 nt2", 2, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VR("r 16x8x8 t4 256 lds w4 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VR("r 4x4x8x8 t4 512 lds w2 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VR("r 4x4x8x8 t4 512 lds w2 nt2", 2, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VR("r 8x8x16 t4 256 lds w4 nt3", 3, float, 1024, 3, 8, 8, 16, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VR("r 16x8x8 t4 256 lds w4 pf nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, true),
+        VR("r 16x8x8 t8 512 lds w2 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+        VR("r 4x4x8x8 t4 512 lds w2 flat nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, false, true, TW_LDS, 2, false),
     };
 #else
 #error "define GROUP"
