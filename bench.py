@@ -26,6 +26,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                  touches the GPU (N=1 default run; else the committed profile of the same command)
   ramp           the untimed clock / cache ramp that precedes the W warm-up steps (ms, execs)
   configs        (N=1) the other four BASELINE.json configs, each timed the same way in this run
+  rfft_reference_bench  (N=1) the shapes of the reference's own GPU benchmark in ITS mode: real input, full complex
+                 spectrum out (fft/bench.mojo:57-97,108-124); fraction of the roofline on 4 B read + 8 B written per point
   cpu_baseline   (N=1) the CPU oracle (restatement of the reference's multi-threaded CPU path) on this host's cores on a
                  bounded sample of the workload, with its 1-thread figure and the SciPy / NumPy comparators of the
                  reference's benchmark-cpu-others/benchmark.py beside it
@@ -72,6 +74,10 @@ DEFAULT_WORKLOAD = "1d_100kx1024_radix2"
 STRONG_WORKLOAD = "3d_10x128x128x128"
 # the BASELINE.json configs other than the headline, in index order (the `configs` array of the N=1 line)
 OTHER_BASELINE_CONFIGS = ["1d_500kx128", "1d_500kx93_radix31x3", "2d_100x640x480", "3d_10x128x128x128"]
+# the shapes the reference's own GPU benchmark runs, which is the REAL-input one (bench_gpu_radix_n_rfft,
+# fft/bench.mojo:57-97, shape list :108-124): real in, full complex spectrum out (`rfft_reference_bench` of the N=1 line)
+RFFT_REFERENCE_SHAPES = [(250000, 93), (250000, 128), (100000, 1024), (100, 640, 480), (100, 64, 64, 64),
+                         (10, 128, 128, 128), (1, 256, 256, 256)]
 RAMP_S = 0.05
 
 
@@ -459,6 +465,25 @@ class Bench:
             },
         }
 
+    def run_real_shape(self, shape, steps, warmup):
+        """real input (C_in = 1) -> full complex spectrum, the mode the reference's bench.mojo times"""
+        torch, mf = self.torch, self.mf
+        gen = torch.Generator(device=self.dev).manual_seed(4321 + self.rank)
+        x = torch.randn(tuple(shape) + (1,), generator=gen, device=self.dev, dtype=self.tdt)
+        out = torch.empty(tuple(shape) + (2,), device=self.dev, dtype=self.tdt)
+        plan = mf.plan_fft(self.tdt, self.tdt, x.shape, out.shape, ctx=self.ctx)
+        elapsed, _, _ = self.timed(lambda: mf.fft(out, x, self.ctx, plan=plan), steps, warmup)
+        launch_ms = mf.time_fft(out, x, plan=plan, iters=max(10, min(steps, 200)), ctx=self.ctx)
+        elems = 1
+        for d in shape:
+            elems *= d
+        algo_bytes = 3.0 * self.esz * elems  # one real read + one complex write per point
+        return {"shape": list(shape) + [1], "ms_per_step": round(elapsed * 1e3 / steps, 5),
+                "launch_ms_hip_events": round(launch_ms, 5),
+                "kernels": [plan.kernel_name(d) for d in range(len(shape) - 1)],
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "roofline_frac": round(algo_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
     # ---- strong scaling: ONE config-5 batch over all ranks (SURVEY.md 8e) ----------------------------
     def strong_leg(self, steps, warmup):
         torch, mf = self.torch, self.mf
@@ -580,6 +605,11 @@ def worker(args, json_out, live_traffic=None):
                 cfgs.append(c)
                 b.torch.cuda.empty_cache()
             result["configs"] = sorted(cfgs, key=lambda c: c["baseline_config_index"])
+            rf = []
+            for shp in RFFT_REFERENCE_SHAPES:
+                rf.append(b.run_real_shape(shp, max(10, min(args.steps, 100)), max(2, min(args.warmup, 10))))
+                b.torch.cuda.empty_cache()
+            result["rfft_reference_bench"] = rf
     if b.rank == 0:
         if b.world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
             result["cpu_baseline"] = cpu_baseline(shape, bases)

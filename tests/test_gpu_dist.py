@@ -98,3 +98,7 @@ def test_bench_single_gpu_line_carries_every_baseline_config():
     for c in d["configs"]:
         assert 0 < c["roofline"]["frac"] < 1 and c["ms_per_step"] > 0 and c["kernels"]
     assert d["strong_config5"]["volumes_per_rank"] == [10]
+    # the reference's own benchmark mode (real input) on its own shapes
+    assert len(d["rfft_reference_bench"]) == 7
+    for c in d["rfft_reference_bench"]:
+        assert c["shape"][-1] == 1 and 0 < c["roofline_frac"] < 1 and "generic" not in c["kernels"]
