@@ -685,6 +685,23 @@ int main(int argc, char** argv) {
         VR("r 16x8x8 t8 512 lds w2 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
         VR("r 4x4x8x8 t4 512 lds w2 flat nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, false, true, TW_LDS, 2, false),
     };
+#elif GROUP == 25  // ---- 8K frame, other orientation: 7680 rows of 4320 ----
+    const long long batch = 7680, outer = 1, inner = 1;
+    const int N = 4320;
+    std::vector<Variant> vs = {
+        V("r4320 10x9x8x6 512 lds w1", float, 4320, 4, 10, 9, 8, 6, 1, 512, false, true, true, TW_LDS, 1, false),
+        V("r4320 10x9x8x6 512 lds w2", float, 4320, 4, 10, 9, 8, 6, 1, 512, false, true, true, TW_LDS, 2, false),
+        V("r4320 10x9x8x6 512 lds w2 pf", float, 4320, 4, 10, 9, 8, 6, 1, 512, false, true, true, TW_LDS, 2, true),
+        V("r4320 10x9x8x6 256 lds w2", float, 4320, 4, 10, 9, 8, 6, 1, 256, false, true, true, TW_LDS, 2, false),
+        V("r4320 10x9x8x6 256 lds w3", float, 4320, 4, 10, 9, 8, 6, 1, 256, false, true, true, TW_LDS, 3, false),
+        V("r4320 16x18x15 256 lds w2", float, 4320, 3, 16, 18, 15, 1, 1, 256, false, true, true, TW_LDS, 2, false),
+        V("r4320 16x18x15 512 lds w2", float, 4320, 3, 16, 18, 15, 1, 1, 512, false, true, true, TW_LDS, 2, false),
+        V("r4320 18x16x15 320 lds w2", float, 4320, 3, 18, 16, 15, 1, 1, 320, false, true, true, TW_LDS, 2, false),
+        V("r4320 12x10x6x6 512 lds w2", float, 4320, 4, 12, 10, 6, 6, 1, 512, false, true, true, TW_LDS, 2, false),
+        V("r4320 10x9x8x6 512 glb w2", float, 4320, 4, 10, 9, 8, 6, 1, 512, false, true, true, TW_GLOBAL, 2, false),
+        V("r4320 10x9x8x6 512 glb w4", float, 4320, 4, 10, 9, 8, 6, 1, 512, false, true, true, TW_GLOBAL, 4, false),
+        V("r4320 10x9x8x6 t2 1024 glb w1", float, 4320, 4, 10, 9, 8, 6, 2, 1024, false, true, true, TW_GLOBAL, 1, false),
+    };
 #else
 #error "define GROUP"
 #endif
