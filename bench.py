@@ -626,6 +626,8 @@ def worker(args, json_out, live_traffic=None):
 
 
 def main():
+    # the host driver of this pool only supports dmabuf IPC: without it RCCL fails in hipIpcGetMemHandle (set before HIP starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     json_out = _claim_stdout()
     args = parse_args()
     if args.gpus < 1:
