@@ -70,6 +70,11 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, true, TW_LDS, 2, false),
     // ---- fp64 (the reference's own tests run in float64, fft/tests.mojo:394-417): same template, 16-byte
     //      elements; smaller butterflies per pass keep the live registers under 128 ----
+    // streaming twins (tools/tune GROUPs 30-32, 100k x 1024 / 500k x 128 / 500k x 93 fp64): 0.631 -> 0.597 ms,
+    // 0.360 -> 0.338 ms, 0.423 -> 0.360 ms
+    MIFFT_CFG_STREAM("rows1024_f64_16x8x8", double, MIFFT_F64, 1024, 3, 16, 8, 8, 1, 2, 128, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_STREAM("rows128_f64_8x16", double, MIFFT_F64, 128, 2, 8, 16, 1, 1, 16, 256, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_STREAM_ST("rows93_f64_31x3_t64", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows1024_f64_4x4x8x8", double, MIFFT_F64, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows512_f64_8x8x8", double, MIFFT_F64, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows256_f64_4x8x8", double, MIFFT_F64, 256, 3, 4, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 1, false),

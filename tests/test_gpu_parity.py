@@ -377,6 +377,36 @@ def test_full_size_real_input(shape):
         assert rel_l2(got[i:i + 1], ref[i:i + 1]) < REL_L2_TOL_F32, (shape, idx[i])
 
 
+@pytest.mark.parametrize("shape,bases", [((20000, 1024), [[2]]), ((150000, 128), None), ((210000, 93), [[31, 3]])])
+def test_streaming_size_fp64(shape, bases):
+    """fp64 tensors beyond the Infinity Cache take the non-temporal twins of the fp64 row kernels."""
+    g = torch.Generator(device=DEV).manual_seed(77)
+    x = torch.randn(shape + (2,), generator=g, device=DEV, dtype=torch.float64)
+    out = torch.full_like(x, float("nan"))
+    ctx = mf.DeviceContext(0)
+    fwd = mf.plan_fft(torch.float64, torch.float64, x.shape, x.shape, bases=bases, ctx=ctx)
+    inv = mf.plan_fft(torch.float64, torch.float64, x.shape, x.shape, bases=bases, inverse=True, ctx=ctx)
+    assert "_nt" in fwd.kernel_name(0), fwd.kernel_name(0)
+    mf.fft(out, x, ctx, plan=fwd)
+    ctx.synchronize()
+    assert not torch.isnan(out).any()
+    b, n = shape
+    ex = (x ** 2).reshape(b, -1).sum(1)
+    eX = (out ** 2).reshape(b, -1).sum(1)
+    assert ((eX / (n * ex) - 1).abs().max().item()) < 1e-12
+    back = torch.full_like(x, float("nan"))
+    mf.fft(back, out, ctx, plan=inv)
+    ctx.synchronize()
+    assert ((back - x).reshape(b, -1).norm(dim=1) / ex.sqrt()).max().item() < 1e-13
+    idx = sorted({0, 1, b // 3, b // 2, b - 2, b - 1, ((b - 1) // 64) * 64})
+    sel = torch.tensor(idx, device=DEV)
+    xs = x.index_select(0, sel).cpu().numpy()
+    ref = O.fftn(xs, bases=bases, out_dtype=np.float64)
+    got = out.index_select(0, sel).cpu().numpy()
+    for i in range(len(idx)):
+        assert rel_l2(got[i:i + 1], ref[i:i + 1]) < REL_L2_TOL_F64, (shape, idx[i])
+
+
 @pytest.mark.parametrize("n,batch,dtype", [(32768, 3, np.float32), (65536, 2, np.float32), (1 << 20, 1, np.float32),
                                            (100000, 3, np.float32), (98304, 2, np.float32), (20480, 5, np.float32),
                                            (50000, 2, np.float64), (1 << 17, 1, np.float64), (1 << 22, 1, np.float32),

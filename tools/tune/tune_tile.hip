@@ -32,6 +32,11 @@ struct Variant {
     size_t lds;
 };
 
+#if GROUP >= 30  // fp64 groups
+using DT = double;
+#else
+using DT = float;
+#endif
 static int g_cus = 256;
 static int g_wg_override = 0;
 #ifdef MIFFT_STAMPS
@@ -702,6 +707,46 @@ int main(int argc, char** argv) {
         V("r4320 10x9x8x6 512 glb w4", float, 4320, 4, 10, 9, 8, 6, 1, 512, false, true, true, TW_GLOBAL, 4, false),
         V("r4320 10x9x8x6 t2 1024 glb w1", float, 4320, 4, 10, 9, 8, 6, 2, 1024, false, true, true, TW_GLOBAL, 1, false),
     };
+#elif GROUP == 30  // ---- fp64: 100k x 1024 (1.6 GB each way) ----
+    const long long batch = 100000, outer = 1, inner = 1;
+    const int N = 1024;
+    std::vector<Variant> vs = {
+        VN("d 4x4x8x8 t2 256 lds w1 nt0", 0, double, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 1, false),
+        VN("d 4x4x8x8 t2 256 lds w1 nt3", 3, double, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 1, false),
+        VN("d 4x4x8x8 t2 256 lds w2 nt3", 3, double, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 2, false),
+        VN("d 4x4x8x8 t4 512 lds w1 nt3", 3, double, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 1, false),
+        VN("d 4x4x8x8 t2 512 lds w2 nt3", 3, double, 1024, 4, 4, 4, 8, 8, 2, 512, false, true, true, TW_LDS, 2, false),
+        VN("d 4x4x4x4x.. 8x8x4x4 t2 256 nt3", 3, double, 1024, 4, 8, 8, 4, 4, 2, 256, false, true, true, TW_LDS, 1, false),
+        VN("d 8x8x16 t2 128 lds w2 nt3", 3, double, 1024, 3, 8, 8, 16, 1, 2, 128, false, true, true, TW_LDS, 2, false),
+        VN("d 16x8x8 t2 128 lds w2 nt3", 3, double, 1024, 3, 16, 8, 8, 1, 2, 128, false, true, true, TW_LDS, 2, false),
+        VN("d 4x4x8x8 t1 128 lds w4 nt3", 3, double, 1024, 4, 4, 4, 8, 8, 1, 128, false, true, true, TW_LDS, 4, false),
+        VN("d 4x4x8x8 t2 256 lds w3 nt3", 3, double, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 3, false),
+    };
+#elif GROUP == 31  // ---- fp64: 500k x 93 ----
+    const long long batch = 500000, outer = 1, inner = 1;
+    const int N = 93;
+    std::vector<Variant> vs = {
+        VN("d93 31x3 t32 96 w1 flat-out nt0", 0, double, 93, 2, 31, 3, 1, 1, 32, 96, false, true, false, TW_LDS, 1, false),
+        VN("d93 31x3 t32 96 w1 flat-out nt2", 2, double, 93, 2, 31, 3, 1, 1, 32, 96, false, true, false, TW_LDS, 1, false),
+        VN("d93 31x3 t64 192 w1 flat-out nt2", 2, double, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 1, false),
+        VN("d93 31x3 t64 192 w2 flat-out nt2", 2, double, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 2, false),
+        VN("d93 31x3 t32 96 w2 flat-out nt2", 2, double, 93, 2, 31, 3, 1, 1, 32, 96, false, true, false, TW_LDS, 2, false),
+        VN("d93 31x3 t21 64 w1 flat-out nt2", 2, double, 93, 2, 31, 3, 1, 1, 21, 64, false, true, false, TW_LDS, 1, false),
+        VN("d93 3x31 t32 96 w1 nt2", 2, double, 93, 2, 3, 31, 1, 1, 32, 96, false, true, false, TW_LDS, 1, false),
+        VN("d93 31x3 t32 96 w1 flat-both nt2", 2, double, 93, 2, 31, 3, 1, 1, 32, 96, false, false, false, TW_LDS, 1, false),
+    };
+#elif GROUP == 32  // ---- fp64: 500k x 128 ----
+    const long long batch = 500000, outer = 1, inner = 1;
+    const int N = 128;
+    std::vector<Variant> vs = {
+        VN("d128 8x4x4 t16 256 w1 nt0", 0, double, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_LDS, 1, false),
+        VN("d128 8x4x4 t16 256 w1 nt3", 3, double, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_LDS, 1, false),
+        VN("d128 8x4x4 t16 256 w2 nt3", 3, double, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_LDS, 2, false),
+        VN("d128 8x4x4 t16 256 reg w2 nt3", 3, double, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 2, false),
+        VN("d128 8x16 t16 256 w2 nt3", 3, double, 128, 2, 8, 16, 1, 1, 16, 256, false, true, true, TW_LDS, 2, false),
+        VN("d128 8x4x4 t8 128 w4 nt3", 3, double, 128, 3, 8, 4, 4, 1, 8, 128, false, true, true, TW_LDS, 4, false),
+        VN("d128 8x4x4 t32 512 w1 nt3", 3, double, 128, 3, 8, 4, 4, 1, 32, 512, false, true, true, TW_LDS, 1, false),
+    };
 #else
 #error "define GROUP"
 #endif
@@ -711,28 +756,28 @@ int main(int argc, char** argv) {
 #else
     const size_t elems = (size_t)batch * outer * inner * N;
 #endif
-    const size_t bytes = elems * 8;
-    std::vector<float> h(elems * 2);
+    const size_t bytes = elems * 2 * sizeof(DT);
+    std::vector<DT> h(elems * 2);
     unsigned s = 12345;
     for (auto& x : h) {
         s = s * 1664525u + 1013904223u;
-        x = ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f;
+        x = (DT)(((s >> 8) & 0xFFFF) / 65536.0f - 0.5f);
     }
-    std::vector<float> tw(2 * N);
+    std::vector<DT> tw(2 * N);
     for (int n = 0; n < N; ++n) {
-        tw[2 * n] = (float)cos(-2.0 * M_PI * n / N);
-        tw[2 * n + 1] = (float)sin(-2.0 * M_PI * n / N);
+        tw[2 * n] = (DT)cos(-2.0 * M_PI * n / N);
+        tw[2 * n + 1] = (DT)sin(-2.0 * M_PI * n / N);
     }
     void *din, *dout, *dref, *dtw;
     CK(hipMalloc(&din, bytes));
     CK(hipMalloc(&dout, bytes));
     CK(hipMalloc(&dref, bytes));
-    CK(hipMalloc(&dtw, tw.size() * 4));
+    CK(hipMalloc(&dtw, tw.size() * sizeof(DT)));
 #ifdef MIFFT_STAMPS
     CK(hipMalloc(&g_stamps, 4096 * 16 * 8));
 #endif
     CK(hipMemcpy(din, h.data(), bytes, hipMemcpyHostToDevice));
-    CK(hipMemcpy(dtw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtw, tw.data(), tw.size() * sizeof(DT), hipMemcpyHostToDevice));
 
     const bool inplace = inner != 1;  // column kernels run in place on `out`
     auto prep = [&](void* dst) {
@@ -741,16 +786,16 @@ int main(int argc, char** argv) {
 
     // correctness vs the first variant (sampled)
     const size_t sample = std::min<size_t>(elems * 2, 1u << 22);
-    std::vector<float> ref(sample), got(sample);
+    std::vector<DT> ref(sample), got(sample);
     prep(dref);
     vs[0].run(inplace ? dref : din, dref, dtw, batch, outer, inner);
     CK(hipDeviceSynchronize());
-    CK(hipMemcpy(ref.data(), dref, sample * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ref.data(), dref, sample * sizeof(DT), hipMemcpyDeviceToHost));
     // tail sample too
-    std::vector<float> ref_tail(sample), got_tail(sample);
-    CK(hipMemcpy(ref_tail.data(), (char*)dref + bytes - sample * 4, sample * 4, hipMemcpyDeviceToHost));
+    std::vector<DT> ref_tail(sample), got_tail(sample);
+    CK(hipMemcpy(ref_tail.data(), (char*)dref + bytes - sample * sizeof(DT), sample * sizeof(DT), hipMemcpyDeviceToHost));
     double refnorm = 0;
-    for (float x : ref) refnorm += (double)x * x;
+    for (DT x : ref) refnorm += (double)x * x;
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -762,8 +807,8 @@ int main(int argc, char** argv) {
         prep(dout);
         vs[i].run(inplace ? dout : din, dout, dtw, batch, outer, inner);
         CK(hipDeviceSynchronize());
-        CK(hipMemcpy(got.data(), dout, sample * 4, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(got_tail.data(), (char*)dout + bytes - sample * 4, sample * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(got.data(), dout, sample * sizeof(DT), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(got_tail.data(), (char*)dout + bytes - sample * sizeof(DT), sample * sizeof(DT), hipMemcpyDeviceToHost));
         double d = 0;
         for (size_t k = 0; k < sample; ++k) {
             double a = (double)got[k] - ref[k], b = (double)got_tail[k] - ref_tail[k];
