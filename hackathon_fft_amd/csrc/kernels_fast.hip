@@ -83,6 +83,12 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_CR("rows93_f64_31x3", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 32, 96, false, true, false, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows480_f64_10x6x8", double, MIFFT_F64, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows640_f64_10x8x8", double, MIFFT_F64, 640, 3, 10, 8, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
+    // tools/tune GROUPs 33 / 35 (fp64 100 x 640 x 480, 10 x 128^3): wave-owned sub-problems + sliced prefetch 0.226 ->
+    // 0.179 ms; 32-column tiles (512-byte runs) 0.135 -> 0.116 ms, 16-column tiles 0.123 ms
+    MIFFT_CFG_WSUB("cols640_f64_10x8x8_ws", double, MIFFT_F64, 640, 3, 10, 8, 8, 1, 8, 640, true, true, true, TW_LDS, 1, true),
+    MIFFT_CFG_WSUB("cols480_f64_10x6x8_ws", double, MIFFT_F64, 480, 3, 10, 6, 8, 1, 8, 640, true, true, true, TW_LDS, 1, true),
+    MIFFT_CFG("cols128_f64_16x8_w32", double, MIFFT_F64, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 2, false),
+    MIFFT_CFG("cols128_f64_16x8_t16", double, MIFFT_F64, 128, 2, 16, 8, 1, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG("cols640_f64_4x4x8x5", double, MIFFT_F64, 640, 4, 4, 4, 8, 5, 8, 256, true, true, true, TW_LDS, 1, false),
     MIFFT_CFG("cols480_f64_4x4x6x5", double, MIFFT_F64, 480, 4, 4, 4, 6, 5, 8, 256, true, true, true, TW_LDS, 1, false),
     MIFFT_CFG("cols128_f64_8x4x4", double, MIFFT_F64, 128, 3, 8, 4, 4, 1, 8, 128, true, true, true, TW_LDS, 1, false),

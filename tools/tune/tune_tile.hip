@@ -242,6 +242,7 @@ Variant make_plane_wp(const char* name) {
 #define V(NAME, ...) make<TileCfg<__VA_ARGS__>>(NAME)
 // wave-owned sub-problems after pass 0 (TileCfg::WSUB)
 #define VW(NAME, ...) make<TileCfg<__VA_ARGS__, 0, false, false, 0, false, float, true>>(NAME)
+#define VWD(NAME, ...) make<TileCfg<__VA_ARGS__, 0, false, false, 0, false, double, true>>(NAME)
 // explicit non-temporal mode: ... PF, then NT (0 none, 1 loads, 2 stores, 3 both)
 #define VN(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, false, false, NT>>(NAME)
 // real input (C_in = 1) promoted in the pass-0 load: ... PF, then NT
@@ -746,6 +747,50 @@ int main(int argc, char** argv) {
         VN("d128 8x16 t16 256 w2 nt3", 3, double, 128, 2, 8, 16, 1, 1, 16, 256, false, true, true, TW_LDS, 2, false),
         VN("d128 8x4x4 t8 128 w4 nt3", 3, double, 128, 3, 8, 4, 4, 1, 8, 128, false, true, true, TW_LDS, 4, false),
         VN("d128 8x4x4 t32 512 w1 nt3", 3, double, 128, 3, 8, 4, 4, 1, 32, 512, false, true, true, TW_LDS, 1, false),
+    };
+#elif GROUP == 33  // ---- fp64 config 4 second pass: columns of 640, inner 480, 100 images ----
+    const long long batch = 100, outer = 1, inner = 480;
+    const int N = 640;
+    std::vector<Variant> vs = {
+        V("dc640 4x4x8x5 t8 256 lds", double, 640, 4, 4, 4, 8, 5, 8, 256, true, true, true, TW_LDS, 1, false),
+        V("dc640 4x4x8x5 t8 512 lds", double, 640, 4, 4, 4, 8, 5, 8, 512, true, true, true, TW_LDS, 1, false),
+        V("dc640 4x4x8x5 t8 512 lds pf", double, 640, 4, 4, 4, 8, 5, 8, 512, true, true, true, TW_LDS, 1, true),
+        V("dc640 10x8x8 t8 512 lds", double, 640, 3, 10, 8, 8, 1, 8, 512, true, true, true, TW_LDS, 1, false),
+        V("dc640 10x8x8 t8 256 lds", double, 640, 3, 10, 8, 8, 1, 8, 256, true, true, true, TW_LDS, 1, false),
+        VWD("dc640 10x8x8 t8 640 wsub", double, 640, 3, 10, 8, 8, 1, 8, 640, true, true, true, TW_LDS, 1, false),
+        VWD("dc640 10x8x8 t8 640 wsub pf", double, 640, 3, 10, 8, 8, 1, 8, 640, true, true, true, TW_LDS, 1, true),
+        VWD("dc640 10x8x8 t8 320 wsub pf", double, 640, 3, 10, 8, 8, 1, 8, 320, true, true, true, TW_LDS, 1, true),
+        VWD("dc640 8x4x4x5 t8 512 wsub pf", double, 640, 4, 8, 4, 4, 5, 8, 512, true, true, true, TW_LDS, 1, true),
+        VWD("dc640 8x4x4x5 t8 512 wsub", double, 640, 4, 8, 4, 4, 5, 8, 512, true, true, true, TW_LDS, 1, false),
+        V("dc640 4x4x8x5 t4 256 lds w2", double, 640, 4, 4, 4, 8, 5, 4, 256, true, true, true, TW_LDS, 2, false),
+    };
+#elif GROUP == 34  // ---- fp64 config 4 first pass: 64000 rows of 480 ----
+    const long long batch = 64000, outer = 1, inner = 1;
+    const int N = 480;
+    std::vector<Variant> vs = {
+        V("dr480 10x6x8 t4 128 lds w1", double, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
+        V("dr480 10x6x8 t4 128 lds w2", double, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 2, false),
+        V("dr480 10x6x8 t4 128 lds w2 pf", double, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 2, true),
+        V("dr480 10x6x8 t8 256 lds w1", double, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 1, false),
+        V("dr480 10x6x8 t8 256 lds w1 pf", double, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 1, true),
+        V("dr480 4x4x5x6 t4 256 lds w2", double, 480, 4, 4, 4, 5, 6, 4, 256, false, true, true, TW_LDS, 2, false),
+        V("dr480 4x4x5x6 t8 512 lds w1", double, 480, 4, 4, 4, 5, 6, 8, 512, false, true, true, TW_LDS, 1, false),
+        VN("dr480 10x6x8 t4 128 w2 nt1", 1, double, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 2, false),
+        V("dr480 8x6x10 t4 128 lds w2", double, 480, 3, 8, 6, 10, 1, 4, 128, false, true, true, TW_LDS, 2, false),
+    };
+#elif GROUP == 35  // ---- fp64 config 5: columns of 128 (inner 16384: z axis; the y axis has inner 128) ----
+    const long long batch = 10, outer = 1, inner = 16384;
+    const int N = 128;
+    std::vector<Variant> vs = {
+        V("dc128 8x4x4 t8 128 lds w1", double, 128, 3, 8, 4, 4, 1, 8, 128, true, true, true, TW_LDS, 1, false),
+        V("dc128 8x4x4 t8 128 lds w4", double, 128, 3, 8, 4, 4, 1, 8, 128, true, true, true, TW_LDS, 4, false),
+        V("dc128 8x16 t8 128 lds w4", double, 128, 2, 8, 16, 1, 1, 8, 128, true, true, true, TW_LDS, 4, false),
+        V("dc128 16x8 t8 128 lds w4", double, 128, 2, 16, 8, 1, 1, 8, 128, true, true, true, TW_LDS, 4, false),
+        V("dc128 16x8 t16 256 lds w4", double, 128, 2, 16, 8, 1, 1, 16, 256, true, true, true, TW_LDS, 4, false),
+        V("dc128 8x4x4 t16 256 lds w4", double, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
+        V("dc128 8x4x4 t16 256 lds w2", double, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 2, false),
+        V("dc128 16x8 t32 512 lds w2", double, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 2, false),
+        V("dc128 8x4x4 t32 512 lds w2", double, 128, 3, 8, 4, 4, 1, 32, 512, true, true, true, TW_LDS, 2, false),
     };
 #else
 #error "define GROUP"
