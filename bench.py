@@ -69,6 +69,10 @@ WORKLOADS = {
     "1d_290kx343_radix7": ((290000, 343), None, -1),
     "1d_330kx97_prime": ((330000, 97), None, -1),
     "2d_3200x100x100_plane": ((3200, 100, 100), None, -1),
+    # real input -> full complex spectrum (the reference's own benchmark mode, fft/bench.mojo:57-97): for profiling
+    "1d_100kx1024_real": ((100000, 1024), [[2]], -1),
+    "2d_100x640x480_real": ((100, 640, 480), None, -1),
+    "3d_10x128x128x128_real": ((10, 128, 128, 128), None, -1),
 }
 DEFAULT_WORKLOAD = "1d_100kx1024_radix2"
 STRONG_WORKLOAD = "3d_10x128x128x128"
@@ -414,20 +418,21 @@ class Bench:
         self.barrier()
         return self.allmax(time.perf_counter() - t0), n_ramp, ramp_s
 
-    def make_input(self, shape, seed_offset=0):
+    def make_input(self, shape, seed_offset=0, comps=2):
         torch = self.torch
         gen = torch.Generator(device=self.dev).manual_seed(1234 + self.rank + seed_offset)
-        x = torch.randn(tuple(shape) + (2,), generator=gen, device=self.dev, dtype=self.tdt)
-        return x, torch.empty_like(x)
+        x = torch.randn(tuple(shape) + (comps,), generator=gen, device=self.dev, dtype=self.tdt)
+        return x, torch.empty(tuple(shape) + (2,), device=self.dev, dtype=self.tdt)
 
     def run_workload(self, name, steps, warmup, plan=None, x=None, out=None):
         """time one workload on this rank's GPU (every rank its own copy of the shape)"""
         mf = self.mf
         shape, bases, cfg_idx = WORKLOADS[name]
+        comps = 1 if name.endswith("_real") else 2
         if x is None:
-            x, out = self.make_input(shape)
+            x, out = self.make_input(shape, comps=comps)
         if plan is None:
-            plan = mf.plan_fft(self.tdt, self.tdt, x.shape, x.shape, bases=bases, ctx=self.ctx,
+            plan = mf.plan_fft(self.tdt, self.tdt, x.shape, out.shape, bases=bases, ctx=self.ctx,
                                faithful_stages=self.args.faithful)
         elapsed, n_ramp, ramp_s = self.timed(lambda: mf.fft(out, x, self.ctx, plan=plan), steps, warmup)
         # kernel-level time: HIP events on the launch stream, inside the library
@@ -436,7 +441,8 @@ class Bench:
         elems = 1
         for d in shape:
             elems *= d
-        algo_bytes = 4.0 * self.esz * elems  # one complex read + one complex write per element, per exec on ONE gpu
+        # one complex (or real) read + one complex write per element, per exec on ONE gpu
+        algo_bytes = (2.0 + comps) * self.esz * elems
         achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
         kernels = [plan.kernel_name(d) for d in range(len(shape) - 1)]
         traffic = measured_traffic(name, kernels)
@@ -447,7 +453,7 @@ class Bench:
                        "live rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command in this run "
                        f"(FETCH_SIZE x {FETCH_FACTOR}, guide 'HBM'); committed: " + (traffic[1] if traffic else "none"), "")
         return {
-            "workload": name, "baseline_config_index": cfg_idx, "shape": list(shape) + [2],
+            "workload": name, "baseline_config_index": cfg_idx, "shape": list(shape) + [comps],
             "ms_per_step": round(ms_per_step, 5),
             "gflops": round(flops_5nlogn(shape) / (ms_per_step * 1e-3) / 1e9, 2),
             "bases": bases if bases is not None else "reference gpu default",
@@ -565,11 +571,12 @@ def worker(args, json_out, live_traffic=None):
             "ms_per_step": main["ms_per_step"], "us_per_transform": round(main["ms_per_step"] * 1e3 / shape[0], 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {
-                "workload": name, "baseline_config_index": cfg_idx, "shape_per_gpu": list(shape) + [2],
+                "workload": name, "baseline_config_index": cfg_idx, "shape_per_gpu": main["shape"],
                 "bases": main["bases"], "stages": main["stages"], "kernels": main["kernels"],
                 "launches_per_step": main["launches_per_step"],
                 "parallelism": f"batch-sharded x{n_gpus}, no data-path collective" + (" (rehearsal: ranks share GPUs)" if b.rehearse else ""),
-                "input": "complex64 N(0,1), seed 1234+rank, resident in HBM",
+                "input": ("real fp N(0,1) (C_in = 1), full complex spectrum out" if name.endswith("_real") else
+                          "complex64 N(0,1)") + ", seed 1234+rank, resident in HBM",
             },
             "roofline": main["roofline"],
         })
