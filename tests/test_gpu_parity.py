@@ -269,6 +269,49 @@ def test_convenience_wrappers():
     mf.clear_plan_cache()
 
 
+# ---- rank 4 and 5 (the reference takes any rank > 2, fft/fft/fft.mojo:20-46; its bench list holds the 4-D 64^4 and the
+#      5-D 25 x 160 x 160 x 48, fft/bench.mojo:120-121) ----
+
+@pytest.mark.parametrize("shape,comps,dtype", [((2, 4, 6, 8, 10), 2, np.float32), ((1, 3, 4, 5, 6, 7), 2, np.float64),
+                                               ((2, 5, 16, 16, 12), 1, np.float32), ((1, 2, 3, 4, 5, 6, 7), 2, np.float32),
+                                               ((3, 7, 9, 11, 13), 2, np.float64), ((1, 6, 10, 64, 64), 1, np.float64)])
+def test_rank_4_to_6_vs_oracle(shape, comps, dtype):
+    rng = np.random.default_rng(len(shape) * 1000 + shape[-1])
+    x = rng.standard_normal(shape + (comps,)).astype(dtype)
+    out, plan = gpu_fft(x, out_dtype=dtype)
+    tol = REL_L2_TOL_F32 if dtype == np.float32 else REL_L2_TOL_F64
+    assert not np.isnan(out).any()
+    assert rel_l2(out, O.fftn(x, out_dtype=dtype)) < tol
+    xc = x[..., 0].astype(np.float64) + (1j * x[..., 1].astype(np.float64) if comps == 2 else 0)
+    truth = np.fft.fftn(xc, axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(truth, np.float64)) < tol
+    back, _ = gpu_fft(out, inverse=True, out_dtype=dtype)
+    want = x if comps == 2 else np.concatenate([x, np.zeros_like(x)], axis=-1)
+    assert rel_l2(back, want) < tol
+
+
+@pytest.mark.parametrize("shape,comps", [((1, 64, 64, 64, 64), 2), ((1, 25, 160, 160, 48), 1), ((1, 25, 160, 160, 48), 2)])
+def test_reference_bench_shapes_of_rank_4_and_5(shape, comps):
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(shape + (comps,), generator=g, device=DEV, dtype=torch.float32)
+    out = torch.full(shape + (2,), float("nan"), device=DEV)
+    ctx = mf.DeviceContext(0)
+    plan = mf.plan_fft(torch.float32, torch.float32, x.shape, out.shape, ctx=ctx)
+    mf.fft(out, x, ctx, plan=plan)
+    ctx.synchronize()
+    assert not torch.isnan(out).any()
+    xh = x.cpu().numpy().astype(np.float64)
+    xc = xh[..., 0] + (1j * xh[..., 1] if comps == 2 else 0)
+    truth = np.fft.fftn(xc, axes=tuple(range(1, len(shape))))
+    assert rel_l2(out.cpu().numpy(), from_complex(truth, np.float64)) < REL_L2_TOL_F32
+    inv = mf.plan_fft(torch.float32, torch.float32, out.shape, out.shape, inverse=True, ctx=ctx)
+    back = torch.full_like(out, float("nan"))
+    mf.fft(back, out, ctx, plan=inv)
+    ctx.synchronize()
+    want = x if comps == 2 else torch.cat([x, torch.zeros_like(x)], dim=-1)
+    assert ((back - want).norm() / want.norm()).item() < 1e-5
+
+
 # ---- full BASELINE sizes: properties that need no CPU reference ----------------------------
 
 FULL_SIZES = [

@@ -1,6 +1,6 @@
 """Randomised end-to-end check of the GPU path against fp64 pocketfft (GPU box):
     python tools/fuzz_gpu.py [cases] [seed]
-Random ranks 1-3, arbitrary lengths (so every kernel family is hit: tables, runtime-specialised rows / column tiles /
+Random ranks 1-5, arbitrary lengths (so every kernel family is hit: tables, runtime-specialised rows / column tiles /
 planes, literal stages, four-step), fp32 / fp64, real / complex / uint8 / int32 input, forward / inverse, ragged batches.
 Prints every failure and a per-family count; exit status 1 on any failure."""
 import os, sys, time, collections
@@ -16,7 +16,7 @@ fam = collections.Counter()
 fails = 0
 t_start = time.time()
 for i in range(cases):
-    nd = int(rng.choice([1, 1, 2, 2, 3]))
+    nd = int(rng.choice([1, 1, 1, 2, 2, 2, 3, 3, 4, 5]))
     if nd == 1:
         n = int(rng.choice([rng.integers(2, 700), rng.integers(2, 5000), 2 ** int(rng.integers(1, 15)), rng.integers(16385, 70000)]))
         shape = (n,)
@@ -24,9 +24,12 @@ for i in range(cases):
     elif nd == 2:
         shape = (int(rng.integers(2, 300)), int(rng.integers(2, 300)))
         batch = int(rng.integers(1, 6))
-    else:
+    elif nd == 3:
         shape = tuple(int(rng.integers(2, 50)) for _ in range(3))
         batch = int(rng.integers(1, 4))
+    else:  # rank 4 / 5 like the reference's commented-out bench shapes (fft/bench.mojo:120-121)
+        shape = tuple(int(rng.integers(2, 20 if nd == 4 else 12)) for _ in range(nd))
+        batch = int(rng.integers(1, 3))
     out_dt = np.float32 if rng.random() < 0.65 else np.float64
     kind = rng.choice(["c", "c", "r", "u8", "i32", "mixed"])
     inverse = bool(rng.random() < 0.3)

@@ -87,6 +87,60 @@ __global__ __launch_bounds__(256) void copy8(const f2* __restrict__ in, f2* __re
     }
 }
 
+// 16 B per lane copy: a wave moves 1 KB per instruction (row-shaped, 8 instructions per 8-KB row)
+template <int NT>
+__global__ __launch_bounds__(256) void copy16(const f4* __restrict__ in, f4* __restrict__ out, int rows) {
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        const f4* p = in + (size_t)r * 512 + lane;
+        f4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];
+        f4* q = out + (size_t)r * 512 + lane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (NT) __builtin_nontemporal_store(v[j], q + j * 64); else q[j * 64] = v[j];
+        }
+    }
+}
+// 16 B loads, 8 B stores and the reverse: which side is it?
+template <int NT>
+__global__ __launch_bounds__(256) void copy16_8(const f4* __restrict__ in, f2* __restrict__ out, int rows) {
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        const f4* p = in + (size_t)r * 512 + lane;
+        f4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];
+        f2* q = out + (size_t)r * 1024 + lane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // (permuted inside the row: timing only)
+            f2 a = {v[j].x, v[j].y}, b = {v[j].z, v[j].w};
+            if (NT) { __builtin_nontemporal_store(a, q + (2 * j) * 64); __builtin_nontemporal_store(b, q + (2 * j + 1) * 64); }
+            else { q[(2 * j) * 64] = a; q[(2 * j + 1) * 64] = b; }
+        }
+    }
+}
+template <int NT>
+__global__ __launch_bounds__(256) void copy8_16(const f2* __restrict__ in, f4* __restrict__ out, int rows) {
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        const f2* p = in + (size_t)r * 1024 + lane;
+        f2 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];
+        f4* q = out + (size_t)r * 512 + lane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f4 a = {v[2 * j].x, v[2 * j].y, v[2 * j + 1].x, v[2 * j + 1].y};
+            if (NT) __builtin_nontemporal_store(a, q + j * 64); else q[j * 64] = a;
+        }
+    }
+}
+
 int main() {
     const int rows = 100000;
     const size_t bytes = (size_t)rows * 1024 * 8;
@@ -115,6 +169,10 @@ int main() {
         time("write-only nt", bytes, [&] { write_only<1><<<blocks, 256>>>((f2*)b, rows); });
         time("copy 8+8", 2.0 * bytes, [&] { copy8<0><<<blocks, 256>>>((f2*)a, (f2*)b, rows); });
         time("copy 8+8 nt", 2.0 * bytes, [&] { copy8<1><<<blocks, 256>>>((f2*)a, (f2*)b, rows); });
+        time("copy 16+16", 2.0 * bytes, [&] { copy16<0><<<blocks, 256>>>((f4*)a, (f4*)b, rows); });
+        time("copy 16+16 nt", 2.0 * bytes, [&] { copy16<1><<<blocks, 256>>>((f4*)a, (f4*)b, rows); });
+        time("copy 16 ld + 8 st nt", 2.0 * bytes, [&] { copy16_8<1><<<blocks, 256>>>((f4*)a, (f2*)b, rows); });
+        time("copy 8 ld + 16 st nt", 2.0 * bytes, [&] { copy8_16<1><<<blocks, 256>>>((f2*)a, (f4*)b, rows); });
         time("promote 4 B loads", 1.5 * bytes, [&] { promote4<0><<<blocks, 256>>>((float*)a, (f2*)b, rows); });
         time("promote 4 B loads nt", 1.5 * bytes, [&] { promote4<1><<<blocks, 256>>>((float*)a, (f2*)b, rows); });
         time("promote 16 B loads", 1.5 * bytes, [&] { promote16<0><<<blocks, 256>>>((float*)a, (f2*)b, rows); });
