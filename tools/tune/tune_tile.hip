@@ -792,6 +792,20 @@ int main(int argc, char** argv) {
         V("dc128 16x8 t32 512 lds w2", double, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 2, false),
         V("dc128 8x4x4 t32 512 lds w2", double, 128, 3, 8, 4, 4, 1, 32, 512, true, true, true, TW_LDS, 2, false),
     };
+#elif GROUP == 26  // ---- config 4 second pass once more: 8-column tiles (64-byte runs, 3 workgroups per CU) with everything round 2 added ----
+    const long long batch = 100, outer = 1, inner = 480;
+    const int N = 640;
+    std::vector<Variant> vs = {
+        VW("c640 10x8x8 t16 640 wsub pf", float, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_LDS, 1, true),
+        VW("c640 10x8x8 t8 320 wsub pf w3", float, 640, 3, 10, 8, 8, 1, 8, 320, true, true, true, TW_LDS, 3, true),
+        VW("c640 10x8x8 t8 320 wsub w3", float, 640, 3, 10, 8, 8, 1, 8, 320, true, true, true, TW_LDS, 3, false),
+        VW("c640 10x8x8 t8 640 wsub w1", float, 640, 3, 10, 8, 8, 1, 8, 640, true, true, true, TW_LDS, 1, false),
+        V("c640 10x8x8 t8 256 lds w3", float, 640, 3, 10, 8, 8, 1, 8, 256, true, true, true, TW_LDS, 3, false),
+        V("c640 10x8x8 t8 256 lds w3 pf", float, 640, 3, 10, 8, 8, 1, 8, 256, true, true, true, TW_LDS, 3, true),
+        V("c640 10x8x8 t8 320 lds w3", float, 640, 3, 10, 8, 8, 1, 8, 320, true, true, true, TW_LDS, 3, false),
+        V("c640 4x4x8x5 t8 256 lds w3", float, 640, 4, 4, 4, 8, 5, 8, 256, true, true, true, TW_LDS, 3, false),
+        V("c640 4x4x8x5 t8 512 lds w2", float, 640, 4, 4, 4, 8, 5, 8, 512, true, true, true, TW_LDS, 2, false),
+    };
 #else
 #error "define GROUP"
 #endif
