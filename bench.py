@@ -643,8 +643,12 @@ def main():
         sys.exit(spawn_ranks(args, json_out))  # nothing in this process has touched torch or the GPU
     live = {}
     headline = (args.workload or DEFAULT_WORKLOAD) == DEFAULT_WORKLOAD and args.scaling == "weak"
+    # never from inside a profiler run: its preloaded tool library has initialised the GPU in THIS process already, and
+    # the child rocprofv3 would exec python3 out of an initialised process (the GPU pool refuses that exec)
+    under_profiler = ("rocprofiler" in os.environ.get("LD_PRELOAD", "") or
+                      any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ))
     if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and headline and not args.no_live_pmc and
-            args.dtype == "f32" and not args.faithful):
+            args.dtype == "f32" and not args.faithful and not under_profiler):
         # child processes under rocprofv3; this process has not touched the GPU yet.  Bounded: one failed or slow pass
         # ends the collection (the committed profiles are the fallback), and the whole of it gets at most 2 minutes
         t_live = time.perf_counter()
