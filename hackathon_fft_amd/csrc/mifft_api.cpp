@@ -339,6 +339,20 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                     }
                 }
             }
+            // tuning knob: strided dimensions of at least MIFFT_FS_STRIDED_MIN_N points try the two-pass four-step before
+            // the single column tile (whose tile narrows to 8 / 4 columns = 64- / 32-byte runs beyond ~1300 / 2600 points)
+            if (!ok && ps.inner != 1) {
+                if (const char* e = getenv("MIFFT_FS_STRIDED_MIN_N")) {
+                    const long long min_n = atoll(e);
+                    std::string whyt;
+                    if (min_n > 0 && (long long)ps.N >= min_n && build_fourstep_strided(p, i, whyt)) continue;
+                    if (p.alloc_failed) {
+                        free_plan_device(p);
+                        delete h;
+                        return set_error(MIFFT_ERR_HIP, "four-step of strided dimension " + std::to_string(i) + ": " + whyt);
+                    }
+                }
+            }
             if (!ok) {
                 std::string whys;
                 ok = select_jit_streaming_rows(p, ps, whys);  // experiment switch, see kernels_jit.cpp
