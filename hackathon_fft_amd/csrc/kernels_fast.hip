@@ -14,34 +14,54 @@ static const FastEntry kFastTable[] = {
     // streaming twin: four small-radix passes, 512 threads x 8 elements (low VGPR count, 32 waves/CU): 0.274 ms
     MIFFT_CFG_STREAM("rows1024_4x4x8x8", float, MIFFT_F32, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM_R("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+    MIFFT_CFG_MID_ST("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+    MIFFT_CFG_MID_ST_R("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
     MIFFT_CFG_CR("rows1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
     // power-of-two rows (tools/tune GROUP 9-12, 819-MB tensors): plain 0.304-0.316 ms, streaming twins 0.277-0.295 ms
     MIFFT_CFG_STREAM("rows512_4x4x4x8", float, MIFFT_F32, 512, 4, 4, 4, 4, 8, 8, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM_R("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_MID_ST("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_MID_ST_R("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM("rows256_8x8x4", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM_R("rows256_8x8x4", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_MID_ST("rows256_8x8x4", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_MID_ST_R("rows256_8x8x4", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows256_8x8x4", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_STREAM_R("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
+    MIFFT_CFG_MID_ST("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
+    MIFFT_CFG_MID_ST_R("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_CR("rows128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
+    MIFFT_CFG_MID_ST("rows64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_REG, 1, false),
+    MIFFT_CFG_MID_ST_R("rows64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_CR("rows64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_REG, 1, false),
     MIFFT_CFG_STREAM("rows2048_4x8x8x8", float, MIFFT_F32, 2048, 4, 4, 8, 8, 8, 2, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM_R("rows2048_16x16x8", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_MID_ST("rows2048_16x16x8", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_MID_ST_R("rows2048_16x16x8", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows2048_16x16x8", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM("rows4096_8x8x8x8", float, MIFFT_F32, 4096, 4, 8, 8, 8, 8, 1, 512, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM_R("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_MID_ST("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_MID_ST_R("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_CR("rows4096_16x16x16", float, MIFFT_F32, 4096, 3, 16, 16, 16, 1, 1, 256, false, true, true, TW_LDS, 2, false),
     // one 128-KiB row per workgroup; twiddles from the global table (the compact LDS table would need 131 KB more)
     MIFFT_CFG("rows16384_16x16x8x8", float, MIFFT_F32, 16384, 4, 16, 16, 8, 8, 1, 1024, false, true, true, TW_GLOBAL, 4, false),
     MIFFT_CFG_STREAM_ST("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
     MIFFT_CFG_STREAM_ST_R("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+    MIFFT_CFG_SMALL_ST("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+    MIFFT_CFG_SMALL_ST_R("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
     MIFFT_CFG_CR("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
     MIFFT_CFG_NTL("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_NTL("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_NTL_R("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_MID_ST("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_MID_ST_R("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_CR("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_NTL_R("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_MID_ST("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_MID_ST_R("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_CR("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     // ---- strided dimensions, fp32 (in place, LDS column tiles) ----
     // ten waves, one per sub-problem of the radix-10 first pass (WSUB): the 8 x 8 passes exchange without workgroup
@@ -247,18 +267,28 @@ bool select_fast_tstore(const Plan& plan, DimPass& pass) {
     return false;
 }
 
+bool nts_window(const Plan& plan, double total_bytes) {
+    double lo = 0.25e9, hi = 0.65e9;
+    if (const char* e = getenv("MIFFT_NTS_MIN_BYTES")) lo = atof(e);
+    if (const char* e = getenv("MIFFT_NTS_MAX_BYTES")) hi = atof(e);
+    return plan.ndim == 1 && total_bytes > lo && total_bytes <= hi;
+}
+
 bool select_fast(const Plan& plan, DimPass& pass) {
     // fast families read real or complex input of the output dtype; integer input and mixed
     // precision run on the generic family
     if (pass.first && plan.in_dtype != plan.out_dtype) return false;
     const bool cols = pass.inner != 1;
     // read + write volume of one exec far beyond the 256-MB Infinity Cache -> non-temporal twins apply
-    const bool streaming = (double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0 > 0.6e9;
+    const double total_bytes = (double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0;
+    const bool streaming = total_bytes > 0.6e9;
     auto try_entry = [&](const FastEntry& e) {
         if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols || e.tstore) return false;
         if (e.in_real != (pass.first && plan.in_components == 1)) return false;
         if (e.stream_pref == 1 && !streaming) return false;
         if (e.stream_pref == 2 && !(plan.cache_resident_nd && pass.first)) return false;
+        if (e.stream_pref == 3 && !nts_window(plan, total_bytes)) return false;
+        if (e.stream_pref == 4 && !(plan.ndim == 1 && total_bytes > 0.05e9)) return false;
         if (cols && e.tile > 16 && pass.inner % e.tile != 0) return false;  // wide tiles: whole tiles only
         // (a strided dimension with fewer columns than one tile still runs here: the ragged tile clamps its loads and
         //  masks its stores; the literal-stage alternative is an order of magnitude slower)

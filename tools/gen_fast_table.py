@@ -173,14 +173,14 @@ def wide_col_cfgs(n, f64=False):
     return res
 
 
-def emit(name, n, f, tile, threads, cols, fd, ld, f64=False, pf=False, tag=""):
+def emit(name, n, f, tile, threads, cols, fd, ld, f64=False, pf=False, tag="", macro="MIFFT_CFG"):
     r = list(f) + [1] * (4 - len(f))
     rs = "x".join(str(v) for v in f) + tag
     ty, dt, suffix = ("double", "MIFFT_F64", "_f64") if f64 else ("float", "MIFFT_F32", "")
     esz = 16 if f64 else 8
     # the compact twiddle table must fit next to the tile (160 KiB per workgroup); else read the global table
     twm = "TW_LDS" if (n * tile + twl_entries(f)) * esz <= 156 * 1024 else "TW_GLOBAL"
-    return (f'    MIFFT_CFG("{name}{n}{suffix}_{rs}", {ty}, {dt}, {n}, {len(f)}, {r[0]}, {r[1]}, {r[2]}, {r[3]}, '
+    return (f'    {macro}("{name}{n}{suffix}_{rs}", {ty}, {dt}, {n}, {len(f)}, {r[0]}, {r[1]}, {r[2]}, {r[3]}, '
             f'{tile}, {threads}, {"true" if cols else "false"}, {"true" if fd else "false"}, '
             f'{"true" if ld else "false"}, {twm}, 1, {"true" if pf else "false"}),')
 
@@ -196,6 +196,8 @@ def main():
         if n not in HAND_ROWS:
             c = row_cfg(n)
             if c:
+                # non-temporal-store twin for the 0.25-0.65 GB window of batched 1-D transforms (fast_table.h), listed first
+                rows.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], pf=len(c) > 5 and c[5], macro="MIFFT_CFG_MID_ST"))
                 rows.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], pf=len(c) > 5 and c[5]))
         if n not in HAND_COLS and n <= 8192:
             for w in wide_col_cfgs(n):   # wide tiles first: select_fast takes the first entry that fits the stride

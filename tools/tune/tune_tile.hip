@@ -273,7 +273,7 @@ int main(int argc, char** argv) {
     g_cus = prop.multiProcessorCount;
 
 #if GROUP == 1  // ---- config 2: 100k x 1024 rows ----
-    const long long batch = 100000, outer = 1, inner = 1;
+    const long long batch = getenv("TUNE_BATCH") ? atoll(getenv("TUNE_BATCH")) : 100000, outer = 1, inner = 1;
     const int N = 1024;
     std::vector<Variant> vs = {
         VN("4x4x8x8 t4 512 lds w2 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
@@ -292,9 +292,12 @@ int main(int argc, char** argv) {
         VN("16x8x8 t4 256 reg w2 pf nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_REG, 2, true),
         VN("4x4x8x8 t4 512 lds w2 nt1", 1, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
         VN("4x4x8x8 t4 512 lds w2 nt0", 0, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("4x4x8x8 t4 512 lds w2 nt2", 2, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        VN("16x8x8 t4 256 lds w4 nt0", 0, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VN("16x8x8 t4 256 lds w4 nt2", 2, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
     };
-#elif GROUP == 2  // ---- config 3: 500k x 93 ----
-    const long long batch = 500000, outer = 1, inner = 1;
+#elif GROUP == 2  // ---- config 3: 500k x 93 (TUNE_BATCH=<rows> for other batch sizes) ----
+    const long long batch = getenv("TUNE_BATCH") ? atoll(getenv("TUNE_BATCH")) : 500000, outer = 1, inner = 1;
     const int N = 93;
     std::vector<Variant> vs = {
         VN("31x3 t64 192 w3 nt2", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, false, false, TW_LDS, 3, false),
@@ -310,8 +313,8 @@ int main(int argc, char** argv) {
         VN("31x3 t64 192 w3 nt2 fd reg", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_REG, 3, false),
         VN("31x3 t85 255 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 85, 255, false, true, false, TW_LDS, 3, false),
     };
-#elif GROUP == 3  // ---- 500k x 128 rows (config 1 shape, config 5 z axis) ----
-    const long long batch = 500000, outer = 1, inner = 1;
+#elif GROUP == 3  // ---- 500k x 128 rows (config 1 shape, config 5 z axis; TUNE_BATCH=<rows>) ----
+    const long long batch = getenv("TUNE_BATCH") ? atoll(getenv("TUNE_BATCH")) : 500000, outer = 1, inner = 1;
     const int N = 128;
     std::vector<Variant> vs = {
         V("8x4x4 t16 reg w1", float, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
@@ -320,6 +323,9 @@ int main(int argc, char** argv) {
         V("16x8 t32 reg w2", float, 128, 2, 16, 8, 1, 1, 32, 256, false, true, true, TW_REG, 2, false),
         V("8x16 t32 reg w2 ldsout", float, 128, 2, 8, 16, 1, 1, 32, 256, false, true, false, TW_REG, 2, false),
         V("16x8 t32 reg w2 ldsin", float, 128, 2, 16, 8, 1, 1, 32, 256, false, false, true, TW_REG, 2, false),
+        VN("8x4x4 t16 reg w1 nt3", 3, float, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
+        VN("8x4x4 t16 reg w1 nt2", 2, float, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
+        VN("8x4x4 t16 reg w1 nt1", 1, float, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_REG, 1, false),
     };
 #elif GROUP == 4  // ---- config 4 second pass: columns of 640, inner 480, 100 images ----
     const long long batch = 100, outer = 1, inner = 480;
