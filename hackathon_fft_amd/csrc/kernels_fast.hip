@@ -95,13 +95,29 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_STREAM("rows1024_f64_16x8x8", double, MIFFT_F64, 1024, 3, 16, 8, 8, 1, 2, 128, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM("rows128_f64_8x16", double, MIFFT_F64, 128, 2, 8, 16, 1, 1, 16, 256, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_STREAM_ST("rows93_f64_31x3_t64", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST("rows1024_f64_4x4x8x8", double, MIFFT_F64, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST_R("rows1024_f64_4x4x8x8", double, MIFFT_F64, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows1024_f64_4x4x8x8", double, MIFFT_F64, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST("rows512_f64_8x8x8", double, MIFFT_F64, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST_R("rows512_f64_8x8x8", double, MIFFT_F64, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows512_f64_8x8x8", double, MIFFT_F64, 512, 3, 8, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST("rows256_f64_4x8x8", double, MIFFT_F64, 256, 3, 4, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST_R("rows256_f64_4x8x8", double, MIFFT_F64, 256, 3, 4, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows256_f64_4x8x8", double, MIFFT_F64, 256, 3, 4, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST("rows128_f64_8x4x4", double, MIFFT_F64, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST_R("rows128_f64_8x4x4", double, MIFFT_F64, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows128_f64_8x4x4", double, MIFFT_F64, 128, 3, 8, 4, 4, 1, 16, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST("rows64_f64_4x4x4", double, MIFFT_F64, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST_R("rows64_f64_4x4x4", double, MIFFT_F64, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows64_f64_4x4x4", double, MIFFT_F64, 64, 3, 4, 4, 4, 1, 32, 256, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_SMALL_ST("rows93_f64_31x3", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 32, 96, false, true, false, TW_LDS, 1, false),
+    MIFFT_CFG_SMALL_ST_R("rows93_f64_31x3", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 32, 96, false, true, false, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows93_f64_31x3", double, MIFFT_F64, 93, 2, 31, 3, 1, 1, 32, 96, false, true, false, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST("rows480_f64_10x6x8", double, MIFFT_F64, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST_R("rows480_f64_10x6x8", double, MIFFT_F64, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows480_f64_10x6x8", double, MIFFT_F64, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST("rows640_f64_10x8x8", double, MIFFT_F64, 640, 3, 10, 8, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
+    MIFFT_CFG_MID_ST_R("rows640_f64_10x8x8", double, MIFFT_F64, 640, 3, 10, 8, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
     MIFFT_CFG_CR("rows640_f64_10x8x8", double, MIFFT_F64, 640, 3, 10, 8, 8, 1, 4, 128, false, true, true, TW_LDS, 1, false),
     // tools/tune GROUPs 33 / 35 (fp64 100 x 640 x 480, 10 x 128^3): wave-owned sub-problems + sliced prefetch 0.226 ->
     // 0.179 ms; 32-column tiles (512-byte runs) 0.135 -> 0.116 ms, 16-column tiles 0.123 ms

@@ -209,6 +209,7 @@ def main():
         if n not in HAND_ROWS_F64:
             c = row_cfg(n, True)
             if c:
+                rows64.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], True, macro="MIFFT_CFG_MID_ST"))
                 rows64.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], True))
         if n not in HAND_COLS_F64 and n <= 2048:
             for w in wide_col_cfgs(n, True):
