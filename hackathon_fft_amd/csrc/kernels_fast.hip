@@ -205,6 +205,7 @@ static int prepare_plane() {
 
 struct PlaneEntry {
     bool ntl;      // non-temporal loads of x: first pass of a cache-resident N-D transform
+    bool nts;      // non-temporal stores: the plane is the ONLY pass (2-D plan) and the batch sits in the window of 3.1c
     bool in_real;  // reads a real (C_in = 1) tensor
     int out_dtype;
     int N1, N2;
@@ -229,6 +230,9 @@ using Plane128C = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, true, false, tr
 using Plane128WR = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true>;
 using Plane128WC = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false>;
 using Plane64RN = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false, 0, false, false, 1>;
+// column sides with non-temporal stores (a 2-D plan whose only pass is the plane)
+using Plane64CS = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, true, false, true, TW_LDS, 2, false, 0, false, false, 2>;
+using Plane128WCS = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false, 0, false, false, 2>;
 // real-input twins (C_in = 1 promoted in the pass-0 load)
 using Plane64RR = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false, 0, true>;
 using Plane128WRR = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true, 0, true>;
@@ -236,17 +240,21 @@ using Plane128WRR = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, false, true, 
 //  register prefetch already keeps the loads far ahead)
 
 static const PlaneEntry kPlaneTable[] = {
-    {true, false, MIFFT_F32, 64, 64, "plane64x64_8x8_ntl", launch_plane<Plane64RN, Plane64C>,
+    {true, false, false, MIFFT_F32, 64, 64, "plane64x64_8x8_ntl", launch_plane<Plane64RN, Plane64C>,
      prepare_plane<Plane64RN, Plane64C>, 512, Plane64RN::LDS_BYTES},
-    {false, false, MIFFT_F32, 64, 64, "plane64x64_8x8", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>,
+    {false, true, false, MIFFT_F32, 64, 64, "plane64x64_8x8_nts", launch_plane<Plane64R, Plane64CS>, prepare_plane<Plane64R, Plane64CS>,
      512, Plane64R::LDS_BYTES},
-    {false, true, MIFFT_F32, 64, 64, "plane64x64_8x8_r", launch_plane<Plane64RR, Plane64C>, prepare_plane<Plane64RR, Plane64C>,
+    {false, false, false, MIFFT_F32, 64, 64, "plane64x64_8x8", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>,
+     512, Plane64R::LDS_BYTES},
+    {false, false, true, MIFFT_F32, 64, 64, "plane64x64_8x8_r", launch_plane<Plane64RR, Plane64C>, prepare_plane<Plane64RR, Plane64C>,
      512, Plane64RR::LDS_BYTES},
     // wave-private exchanges (plane_kernel_wp): 2 workgroup barriers per plane instead of 12; 1280 planes 0.0812 ->
     // 0.0744 ms (tools/tune GROUP 7).  For 64 x 64 planes (four workgroups per CU already overlap) it ties.
-    {false, false, MIFFT_F32, 128, 128, "plane128x128_8x16_wp", launch_plane_wp<Plane128WR, Plane128WC, 8>,
+    {false, true, false, MIFFT_F32, 128, 128, "plane128x128_8x16_wp_nts", launch_plane_wp<Plane128WR, Plane128WCS, 8>,
+     prepare_plane_wp<Plane128WR, Plane128WCS, 8>, 1024, WavePlane<Plane128WR, Plane128WCS, 8>::LDS_BYTES},
+    {false, false, false, MIFFT_F32, 128, 128, "plane128x128_8x16_wp", launch_plane_wp<Plane128WR, Plane128WC, 8>,
      prepare_plane_wp<Plane128WR, Plane128WC, 8>, 1024, WavePlane<Plane128WR, Plane128WC, 8>::LDS_BYTES},
-    {false, true, MIFFT_F32, 128, 128, "plane128x128_8x16_wp_r", launch_plane_wp<Plane128WRR, Plane128WC, 8>,
+    {false, false, true, MIFFT_F32, 128, 128, "plane128x128_8x16_wp_r", launch_plane_wp<Plane128WRR, Plane128WC, 8>,
      prepare_plane_wp<Plane128WRR, Plane128WC, 8>, 1024, WavePlane<Plane128WRR, Plane128WC, 8>::LDS_BYTES},
 };
 
@@ -256,6 +264,8 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
         if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
         if (e.in_real != (pass.first && plan.in_components == 1)) continue;
         if (e.ntl && !(plan.cache_resident_nd && plan.ndim > 2)) continue;  // a 2-D plane is the only pass: nothing to keep
+        if (e.nts && !(plan.ndim == 2 && nts_window_bytes((double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0)))
+            continue;
         pass.kernel_name = e.name;
         pass.launch = e.launch;
         pass.prepare = e.prepare;
@@ -283,12 +293,13 @@ bool select_fast_tstore(const Plan& plan, DimPass& pass) {
     return false;
 }
 
-bool nts_window(const Plan& plan, double total_bytes) {
+bool nts_window_bytes(double total_bytes) {
     double lo = 0.25e9, hi = 0.65e9;
     if (const char* e = getenv("MIFFT_NTS_MIN_BYTES")) lo = atof(e);
     if (const char* e = getenv("MIFFT_NTS_MAX_BYTES")) hi = atof(e);
-    return plan.ndim == 1 && total_bytes > lo && total_bytes <= hi;
+    return total_bytes > lo && total_bytes <= hi;
 }
+bool nts_window(const Plan& plan, double total_bytes) { return plan.ndim == 1 && nts_window_bytes(total_bytes); }
 
 bool select_fast(const Plan& plan, DimPass& pass) {
     // fast families read real or complex input of the output dtype; integer input and mixed

@@ -110,6 +110,7 @@ bool select_jit_streaming_rows(const Plan& plan, DimPass& pass, std::string& why
 // the non-temporal-store window of batched 1-D transforms (bytes moved per exec, kernels_fast.hip);
 // MIFFT_NTS_MIN_BYTES / MIFFT_NTS_MAX_BYTES are tuning knobs
 bool nts_window(const Plan& plan, double total_bytes);
+bool nts_window_bytes(double total_bytes);  // the same window without the one-dimension condition (single-pass planes)
 bool select_jit_plane(const Plan& plan, DimPass& pass, std::string& why_not);
 // the two innermost dimensions of images that fit one XCD's L2: rows, XCD-local barrier, columns from L2
 bool select_jit_image(const Plan& plan, DimPass& pass, std::string& why_not);
