@@ -420,6 +420,43 @@ def test_full_size_real_input(shape):
         assert rel_l2(got[i:i + 1], ref[i:i + 1]) < REL_L2_TOL_F32, (shape, idx[i])
 
 
+# batches in the 0.25-0.65 GB window take the non-temporal-store twins: table, generated table,
+# runtime-specialised lengths, fp64, and planes that are a 2-D plan's only pass
+WINDOW_CASES = [((250000, 93), torch.float32), ((250000, 128), torch.float32), ((30000, 1024), torch.float32),
+                ((25000, 1000), torch.float32), ((70000, 343), torch.float32), ((100000, 128), torch.float64),
+                ((12000, 1000), torch.float64), ((6400, 64, 64), torch.float32), ((1600, 128, 128), torch.float32),
+                ((2600, 100, 100), torch.float32)]
+
+
+@pytest.mark.parametrize("shape,dtype", WINDOW_CASES)
+def test_store_policy_window_twins(shape, dtype):
+    g = torch.Generator(device=DEV).manual_seed(31)
+    x = torch.randn(shape + (2,), generator=g, device=DEV, dtype=dtype)
+    out = torch.full_like(x, float("nan"))
+    ctx = mf.DeviceContext(0)
+    plan = mf.plan_fft(dtype, dtype, x.shape, x.shape, ctx=ctx)
+    assert "_nts" in plan.kernel_name(len(shape) - 2), [plan.kernel_name(d) for d in range(len(shape) - 1)]
+    mf.fft(out, x, ctx, plan=plan)
+    ctx.synchronize()
+    assert not torch.isnan(out).any()
+    b = shape[0]
+    idx = sorted({0, 1, b // 3, b // 2, b - 2, b - 1, ((b - 1) // 64) * 64})
+    sel = torch.tensor(idx, device=DEV)
+    xs = x.index_select(0, sel).cpu().numpy()
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    ref = O.fftn(xs, out_dtype=np_dt)
+    got = out.index_select(0, sel).cpu().numpy()
+    tol = REL_L2_TOL_F32 if dtype == torch.float32 else REL_L2_TOL_F64
+    for i in range(len(idx)):
+        assert rel_l2(got[i:i + 1], ref[i:i + 1]) < tol, (shape, idx[i])
+    inv = mf.plan_fft(dtype, dtype, x.shape, x.shape, inverse=True, ctx=ctx)
+    back = torch.full_like(x, float("nan"))
+    mf.fft(back, out, ctx, plan=inv)
+    ctx.synchronize()
+    err = ((back.double() - x.double()).reshape(b, -1).norm(dim=1) / x.double().reshape(b, -1).norm(dim=1)).max().item()
+    assert err < (1e-5 if dtype == torch.float32 else 1e-13)
+
+
 @pytest.mark.parametrize("shape,bases", [((20000, 1024), [[2]]), ((150000, 128), None), ((210000, 93), [[31, 3]])])
 def test_streaming_size_fp64(shape, bases):
     """fp64 tensors beyond the Infinity Cache take the non-temporal twins of the fp64 row kernels."""
