@@ -77,6 +77,10 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_TS("cols2048_8x16x16", float, MIFFT_F32, 2048, 3, 8, 16, 16, 1, 8, 512, true, true, false, TW_LDS, 1, false),
     MIFFT_CFG_TS("cols1024_16x8x8", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 16, 512, true, true, false, TW_LDS, 1, false),
     MIFFT_CFG_TS("cols512_8x8x8", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 16, 512, true, true, false, TW_LDS, 1, false),
+    // 32-column tiles for the four-step first pass (256-byte runs on the read side; whole tiles only): 3906 x 16384
+    // 0.412 -> 0.398 ms, 976 x 65536 0.405 -> 0.401 ms; 64 columns lose (0.420)
+    MIFFT_CFG_TS("cols256_16x16_w32", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 32, 512, true, true, false, TW_LDS, 2, false),
+    MIFFT_CFG_TS("cols128_16x8_w32", float, MIFFT_F32, 128, 2, 16, 8, 1, 1, 32, 512, true, true, false, TW_LDS, 4, false),
     MIFFT_CFG_TS("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, false, TW_LDS, 2, false),
     MIFFT_CFG_TS("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, false, TW_LDS, 4, false),
     MIFFT_CFG_TS("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, false, TW_LDS, 4, false),
@@ -281,6 +285,7 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
 bool select_fast_tstore(const Plan& plan, DimPass& pass) {
     for (const FastEntry& e : kFastTable) {
         if (!e.tstore || e.out_dtype != plan.out_dtype || e.N != pass.N || pass.inner < e.tile) continue;
+        if (e.tile > 16 && pass.inner % e.tile != 0) continue;  // wide tiles: whole tiles only
         pass.kernel_name = e.name;
         pass.launch = e.launch;
         pass.prepare = e.prepare;
