@@ -59,7 +59,7 @@ struct FastEntry {
     bool in_real;     // the kernel promotes a real (C_in = 1) tensor in its pass-0 load
     int stream_pref;  // 1: only for streaming-size problems (non-temporal twin), 2: only as the first pass of a
                       // cache-resident N-D transform (non-temporal LOADS), 3 / 4: batched 1-D transforms that move
-                      // 0.25-0.65 GB / more than 0.05 GB per exec (non-temporal STORES), -1: any size
+                      // 0.25-0.55 GB / more than 0.05 GB per exec (non-temporal STORES), -1: any size
     int out_dtype;
     int N;
     bool cols;
@@ -102,10 +102,10 @@ struct FastEntry {
 #define MIFFT_CFG_STREAM_ST_R(NAME, ...) MIFFT_CFG_X(false, true, 2, 1, NAME "_r_nts", __VA_ARGS__)
 #define MIFFT_CFG_NTL_R(NAME, ...) MIFFT_CFG_X(false, true, 1, 2, NAME "_r_ntl", __VA_ARGS__)
 // ... non-temporal STORES for batched 1-D transforms in the window where plain stores thrash the 256-MB Infinity Cache
-// (stream_pref 3: ONE dimension, 0.25 ... 0.65 GB moved per exec): the output is not read again by this plan, and keeping
+// (stream_pref 3: ONE dimension, 0.25 ... 0.55 GB moved per exec): the output is not read again by this plan, and keeping
 // it out of the cache leaves the cache to the loads.  30k x 1024 0.0935 -> 0.0756 ms, 250k x 128 0.0893 -> 0.0778,
 // generated lengths 49 ... 3125 at 0.4 GB 6-20 % faster; neutral or slower below 0.25 GB and (for the generated
-// configurations) above 0.65 GB (tools/tune GROUPs 1-3 with TUNE_BATCH, tools/nts_probe.py).  Non-temporal LOADS lose below
+// configurations) above 0.55 GB (tools/tune GROUPs 1-3 with TUNE_BATCH, tools/nts_probe.py).  Non-temporal LOADS lose below
 // ~0.6 GB and stay with the streaming twins above.  N-D plans never take these: their later passes read `out` back.
 #define MIFFT_CFG_MID_ST(NAME, ...) MIFFT_CFG_X(false, false, 2, 3, NAME "_nts", __VA_ARGS__)
 #define MIFFT_CFG_MID_ST_R(NAME, ...) MIFFT_CFG_X(false, true, 2, 3, NAME "_r_nts", __VA_ARGS__)

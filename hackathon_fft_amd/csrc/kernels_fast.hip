@@ -299,7 +299,7 @@ bool select_fast_tstore(const Plan& plan, DimPass& pass) {
 }
 
 bool nts_window_bytes(double total_bytes) {
-    double lo = 0.25e9, hi = 0.65e9;
+    double lo = 0.25e9, hi = 0.55e9;
     if (const char* e = getenv("MIFFT_NTS_MIN_BYTES")) lo = atof(e);
     if (const char* e = getenv("MIFFT_NTS_MAX_BYTES")) hi = atof(e);
     return total_bytes > lo && total_bytes <= hi;

@@ -197,7 +197,10 @@ def main():
             c = row_cfg(n)
             if c:
                 # non-temporal-store twin for the 0.25-0.65 GB window of batched 1-D transforms (fast_table.h), listed first
-                rows.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], pf=len(c) > 5 and c[5], macro="MIFFT_CFG_MID_ST"))
+                # (not when the last pass stores short runs that are no whole number of 128-byte lines: kernels_jit.cpp)
+                run = (n // c[0][-1]) * 8
+                if (not c[4]) or run % 128 == 0 or run >= 512:
+                    rows.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], pf=len(c) > 5 and c[5], macro="MIFFT_CFG_MID_ST"))
                 rows.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], pf=len(c) > 5 and c[5]))
         if n not in HAND_COLS and n <= 8192:
             for w in wide_col_cfgs(n):   # wide tiles first: select_fast takes the first entry that fits the stride
@@ -209,7 +212,9 @@ def main():
         if n not in HAND_ROWS_F64:
             c = row_cfg(n, True)
             if c:
-                rows64.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], True, macro="MIFFT_CFG_MID_ST"))
+                run = (n // c[0][-1]) * 16
+                if (not c[4]) or run % 128 == 0 or run >= 512:
+                    rows64.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], True, macro="MIFFT_CFG_MID_ST"))
                 rows64.append(emit("rows", n, c[0], c[1], c[2], False, c[3], c[4], True))
         if n not in HAND_COLS_F64 and n <= 2048:
             for w in wide_col_cfgs(n, True):
