@@ -196,7 +196,7 @@ def main():
         if n not in HAND_ROWS:
             c = row_cfg(n)
             if c:
-                # non-temporal-store twin for the 0.25-0.65 GB window of batched 1-D transforms (fast_table.h), listed first
+                # non-temporal-store twin for the 0.25-0.55 GB window of batched 1-D transforms (fast_table.h), listed first
                 # (not when the last pass stores short runs that are no whole number of 128-byte lines: kernels_jit.cpp)
                 run = (n // c[0][-1]) * 8
                 if (not c[4]) or run % 128 == 0 or run >= 512:
