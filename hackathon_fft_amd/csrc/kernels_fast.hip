@@ -314,12 +314,16 @@ bool select_fast(const Plan& plan, DimPass& pass) {
     // read + write volume of one exec far beyond the 256-MB Infinity Cache -> non-temporal twins apply
     const double total_bytes = (double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0;
     const bool streaming = total_bytes > 0.6e9;
+    bool hand_table = true;  // the hand-tuned lengths keep their `_nts` twins up to the streaming threshold (0.6 GB), where
+                             // the `_nt` twins take over: 50k x 1024 still gains 4-6 % with non-temporal stores
     auto try_entry = [&](const FastEntry& e) {
         if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols || e.tstore) return false;
         if (e.in_real != (pass.first && plan.in_components == 1)) return false;
         if (e.stream_pref == 1 && !streaming) return false;
         if (e.stream_pref == 2 && !(plan.cache_resident_nd && pass.first)) return false;
-        if (e.stream_pref == 3 && !nts_window(plan, total_bytes)) return false;
+        if (e.stream_pref == 3 && !(nts_window(plan, total_bytes) ||
+                                    (hand_table && plan.ndim == 1 && total_bytes > 0.25e9 && !streaming)))
+            return false;
         if (e.stream_pref == 4 && !(plan.ndim == 1 && total_bytes > 0.05e9)) return false;
         if (cols && e.tile > 16 && pass.inner % e.tile != 0) return false;  // wide tiles: whole tiles only
         // (a strided dimension with fewer columns than one tile still runs here: the ragged tile clamps its loads and
@@ -335,6 +339,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
     };
     for (const FastEntry& e : kFastTable)  // hand-tuned entries win
         if (try_entry(e)) return true;
+    hand_table = false;
     int ngen = 0;
     const FastEntry* gen;
     if (plan.out_dtype == MIFFT_F64)
