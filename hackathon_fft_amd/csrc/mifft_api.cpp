@@ -265,7 +265,12 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
         double max_mb = 250.0;
         if (const char* ev = getenv("MIFFT_ND_CACHE_MAX_MB")) max_mb = atof(ev);
         const double out_bytes = (double)batch * (double)p.prod * (double)p.out_elem_bytes();
-        p.cache_resident_nd = ndim >= 2 && (nd_mode & 1) && out_bytes <= max_mb * 1e6;
+        // ... and only when x and out together do NOT fit: below ~160 MB per tensor everything stays cache-resident
+        // between the passes (and between execs), and non-temporal loads of x cost 6-9 % (100-image batches of
+        // 640 x 480 at 59 / 118 MB: 0.0510 -> 0.0551 / 0.0834 -> 0.0905 ms, 64^3 the same; tools/nd_size_probe.py)
+        double min_mb = 160.0;
+        if (const char* ev = getenv("MIFFT_ND_CACHE_MIN_MB")) min_mb = atof(ev);
+        p.cache_resident_nd = ndim >= 2 && (nd_mode & 1) && out_bytes <= max_mb * 1e6 && out_bytes >= min_mb * 1e6;
     }
 
     // ---- passes in execution order: last dimension first ----
