@@ -234,14 +234,13 @@ using Plane128C = TileCfg<float, 128, 2, 16, 8, 1, 1, 128, 1024, true, false, tr
 using Plane128WR = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true>;
 using Plane128WC = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false>;
 using Plane64RN = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false, 0, false, false, 1>;
+using Plane128WRN = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true, 0, false, false, 1>;
 // column sides with non-temporal stores (a 2-D plan whose only pass is the plane)
 using Plane64CS = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, true, false, true, TW_LDS, 2, false, 0, false, false, 2>;
 using Plane128WCS = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false, 0, false, false, 2>;
 // real-input twins (C_in = 1 promoted in the pass-0 load)
 using Plane64RR = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false, 0, true>;
 using Plane128WRR = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true, 0, true>;
-// (a non-temporal twin of the 128 x 128 plane measured SLOWER: 75.5 -> 80.5 us for 1280 planes; its next-plane
-//  register prefetch already keeps the loads far ahead)
 
 static const PlaneEntry kPlaneTable[] = {
     {true, false, false, MIFFT_F32, 64, 64, "plane64x64_8x8_ntl", launch_plane<Plane64RN, Plane64C>,
@@ -254,6 +253,10 @@ static const PlaneEntry kPlaneTable[] = {
      512, Plane64RR::LDS_BYTES},
     // wave-private exchanges (plane_kernel_wp): 2 workgroup barriers per plane instead of 12; 1280 planes 0.0812 ->
     // 0.0744 ms (tools/tune GROUP 7).  For 64 x 64 planes (four workgroups per CU already overlap) it ties.
+    // (next-plane register prefetch already keeps its loads far ahead: the hint pays only from ~210 MB per tensor --
+    //  168 / 185 / 235 MB: 0.1164 / 0.1296 / 0.1671 ms plain, 0.1177 / 0.1325 / 0.1588 ms with it)
+    {true, false, false, MIFFT_F32, 128, 128, "plane128x128_8x16_wp_ntl", launch_plane_wp<Plane128WRN, Plane128WC, 8>,
+     prepare_plane_wp<Plane128WRN, Plane128WC, 8>, 1024, WavePlane<Plane128WRN, Plane128WC, 8>::LDS_BYTES},
     {false, true, false, MIFFT_F32, 128, 128, "plane128x128_8x16_wp_nts", launch_plane_wp<Plane128WR, Plane128WCS, 8>,
      prepare_plane_wp<Plane128WR, Plane128WCS, 8>, 1024, WavePlane<Plane128WR, Plane128WCS, 8>::LDS_BYTES},
     {false, false, false, MIFFT_F32, 128, 128, "plane128x128_8x16_wp", launch_plane_wp<Plane128WR, Plane128WC, 8>,
@@ -268,6 +271,7 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
         if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
         if (e.in_real != (pass.first && plan.in_components == 1)) continue;
         if (e.ntl && !(plan.cache_resident_nd && plan.ndim > 2)) continue;  // a 2-D plane is the only pass: nothing to keep
+        if (e.ntl && e.N1 == 128 && (double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() < 210e6) continue;
         if (e.nts && !(plan.ndim == 2 && nts_window_bytes((double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0)))
             continue;
         pass.kernel_name = e.name;
