@@ -19,7 +19,7 @@ EXPORTS = (
     "mifft_plan_kernel_name", "mifft_plan_num_launches", "mifft_plan_in_bytes", "mifft_plan_out_bytes",
     "mifft_ordered_bases", "mifft_estimate_bases", "mifft_last_error", "mifft_status_string",
     "mifft_version", "mifft_device_count", "mifft_time_exec", "mifft_jit_precompile", "mifft_plan_scratch_bytes",
-    "mifft_plan_device_status",
+    "mifft_plan_device_status", "mifft_plan_create_slab",
 )
 
 
@@ -52,6 +52,9 @@ def lib() -> ctypes.CDLL:
     L.mifft_plan_create.argtypes = [c.POINTER(vp), c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(i64), i64,
                                     c.c_int, c.c_int, u32p, i32p, c.c_uint32]
     L.mifft_plan_create.restype = c.c_int
+    L.mifft_plan_create_slab.argtypes = [c.POINTER(vp), c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(i64), i64,
+                                         c.c_int, c.c_int, u32p, i32p, c.c_uint32, i64]
+    L.mifft_plan_create_slab.restype = c.c_int
     L.mifft_exec.argtypes = [vp, vp, vp, vp]
     L.mifft_exec_batch.argtypes = [vp, vp, vp, i64, i64, vp]
     L.mifft_plan_destroy.argtypes = [vp]

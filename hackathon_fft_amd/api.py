@@ -110,7 +110,7 @@ class Plan:
     """_GPUPlan (fft/fft/_ndim_fft_gpu.mojo:153-207): owns the device twiddle tables."""
 
     def __init__(self, in_dtype, out_dtype, in_shape, out_shape, *, bases=None, inverse=False,
-                 device: int = 0, flags: int = 0):
+                 device: int = 0, flags: int = 0, whole_batch: int = 0):
         in_shape, out_shape = tuple(int(v) for v in in_shape), tuple(int(v) for v in out_shape)
         _check_layout_conditions_nd(in_shape, out_shape)
         if in_dtype not in _DTYPE_CODE or out_dtype not in _DTYPE_CODE:
@@ -130,9 +130,11 @@ class Plan:
         else:
             c_flat, c_len = None, None
         h = ctypes.c_void_p()
-        check(_lib.lib().mifft_plan_create(ctypes.byref(h), self.device, _DTYPE_CODE[in_dtype],
-                                           _DTYPE_CODE[out_dtype], len(dims), c_dims, out_shape[0], in_shape[-1],
-                                           int(self.inverse), c_flat, c_len, self.flags))
+        # whole_batch > 0: this plan is one slab of a batch of that many transforms (mifft_plan_create_slab)
+        self.whole_batch = int(whole_batch)
+        check(_lib.lib().mifft_plan_create_slab(ctypes.byref(h), self.device, _DTYPE_CODE[in_dtype],
+                                                _DTYPE_CODE[out_dtype], len(dims), c_dims, out_shape[0], in_shape[-1],
+                                                int(self.inverse), c_flat, c_len, self.flags, self.whole_batch))
         self._h = h
 
     # -- introspection ------------------------------------------------------
@@ -190,19 +192,22 @@ class Plan:
 def plan_fft(in_dtype, out_dtype, in_layout: Sequence[int], out_layout: Sequence[int], *, bases=None,
              inverse: bool = False, runtime_twfs: bool = True, max_cluster_size: int = 8,
              _test: Optional[GPUTest] = None, faithful_stages: bool = False,
-             ctx: Optional[DeviceContext] = None) -> Plan:
+             ctx: Optional[DeviceContext] = None, whole_batch: int = 0) -> Plan:
     """GPU overload of plan_fft (fft/fft/fft.mojo:161-210).
 
     ``runtime_twfs`` and ``max_cluster_size`` are accepted for call-site compatibility
     and ignored: twiddles always come from an fp64-accurate device table and CDNA4
     has no thread-block clusters.  ``bases=None`` selects the reference's GPU default.
+    ``whole_batch`` (no reference counterpart): this plan covers one slab of a batch of that many transforms split over
+    several plans / GPUs; size-dependent kernel choices follow the whole batch, so the slab's results equal the same
+    rows of one plan over the whole batch bit for bit.
     """
     del runtime_twfs, max_cluster_size
     if ctx is None:
         ctx = DeviceContext()
     flags = FLAG_FAITHFUL_STAGES if (faithful_stages or _test is not None) else 0
     return Plan(in_dtype, out_dtype, in_layout, out_layout, bases=bases, inverse=inverse,
-                device=ctx.device, flags=flags)
+                device=ctx.device, flags=flags, whole_batch=whole_batch)
 
 
 def _check_tensor(t: "torch.Tensor", shape: tuple, dtype, device: int, what: str) -> None:

@@ -158,7 +158,7 @@ bool select_dpp_rows(const Plan& plan, DimPass& pass) {
     if (pass.inner != 1 || !pass.first || plan.out_dtype != MIFFT_F32 || plan.in_dtype != MIFFT_F32 ||
         plan.in_components != 2)
         return false;
-    const bool streaming = (double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0 > 0.6e9;
+    const bool streaming = plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0 > 0.6e9;
     int variant = 0;  // tuning knob: 0 = 16 rows per wave, 1 = 20 rows per wave; +2 = plain stores at streaming sizes
     if (const char* e = getenv("MIFFT_DPP_VARIANT")) variant = atoi(e);
     const bool nt = streaming && !(variant & 2);

@@ -271,8 +271,8 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
         if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
         if (e.in_real != (pass.first && plan.in_components == 1)) continue;
         if (e.ntl && !(plan.cache_resident_nd && plan.ndim > 2)) continue;  // a 2-D plane is the only pass: nothing to keep
-        if (e.ntl && e.N1 == 128 && (double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() < 210e6) continue;
-        if (e.nts && !(plan.ndim == 2 && nts_window_bytes((double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0)))
+        if (e.ntl && e.N1 == 128 && plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() < 210e6) continue;
+        if (e.nts && !(plan.ndim == 2 && nts_window_bytes(plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0)))
             continue;
         pass.kernel_name = e.name;
         pass.launch = e.launch;
@@ -316,7 +316,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
     if (pass.first && plan.in_dtype != plan.out_dtype) return false;
     const bool cols = pass.inner != 1;
     // read + write volume of one exec far beyond the 256-MB Infinity Cache -> non-temporal twins apply
-    const double total_bytes = (double)plan.batch * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0;
+    const double total_bytes = plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0;
     const bool streaming = total_bytes > 0.6e9;
     bool hand_table = true;  // the hand-tuned lengths keep their `_nts` twins up to the streaming threshold (0.6 GB), where
                              // the `_nt` twins take over: 50k x 1024 still gains 4-6 % with non-temporal stores

@@ -166,7 +166,19 @@ int mifft_estimate_bases(uint32_t length, int target_gpu, uint32_t* bases_out, i
 int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_dtype, int ndim,
                       const int64_t* dims, int64_t batch, int in_components, int inverse,
                       const uint32_t* bases_flat, const int32_t* bases_len, uint32_t flags) {
+    return mifft_plan_create_slab(out_plan, device, in_dtype, out_dtype, ndim, dims, batch, in_components, inverse,
+                                  bases_flat, bases_len, flags, 0);
+}
+
+int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int out_dtype, int ndim,
+                           const int64_t* dims, int64_t batch, int in_components, int inverse,
+                           const uint32_t* bases_flat, const int32_t* bases_len, uint32_t flags,
+                           int64_t whole_batch) {
     if (!out_plan) return set_error(MIFFT_ERR_NULL, "out_plan is NULL");
+    if (whole_batch != 0 && whole_batch < batch) {
+        *out_plan = nullptr;
+        return set_error(MIFFT_ERR_BAD_BATCH, "whole_batch must be 0 or >= batch");
+    }
     *out_plan = nullptr;
     // ---- validation = _check_layout_conditions_nd (fft/fft/fft.mojo:20-46) ----
     if (ndim < 1 || ndim > MIFFT_MAX_DIMS)
@@ -190,6 +202,7 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
     p.out_dtype = out_dtype;
     p.ndim = ndim;
     p.batch = batch;
+    p.sel_batch = whole_batch;
     p.in_components = in_components;
     p.inverse = inverse ? 1 : 0;
     p.flags = flags;
@@ -264,7 +277,7 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
     {
         double max_mb = 250.0;
         if (const char* ev = getenv("MIFFT_ND_CACHE_MAX_MB")) max_mb = atof(ev);
-        const double out_bytes = (double)batch * (double)p.prod * (double)p.out_elem_bytes();
+        const double out_bytes = p.size_batch() * (double)p.prod * (double)p.out_elem_bytes();
         // ... and only when x and out together do NOT fit: below ~160 MB per tensor everything stays cache-resident
         // between the passes (and between execs), and non-temporal loads of x cost 6-9 % (100-image batches of
         // 640 x 480 at 59 / 118 MB: 0.0510 -> 0.0551 / 0.0834 -> 0.0905 ms, 64^3 the same; tools/nd_size_probe.py)
@@ -318,7 +331,7 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
             if (!ok && ndim == 1 && p.in_components == 2 && p.in_dtype == p.out_dtype) {
                 long long min_n = 16384;
                 if (const char* e = getenv("MIFFT_FOURSTEP_MIN_N")) min_n = atoll(e);
-                const double bytes = (double)batch * (double)ps.N * (double)p.out_elem_bytes();
+                const double bytes = p.size_batch() * (double)ps.N * (double)p.out_elem_bytes();
                 if (min_n > 0 && ps.N >= min_n && bytes >= 32e6) {
                     std::string why4;
                     const size_t before = p.passes.size();

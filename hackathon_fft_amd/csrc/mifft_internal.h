@@ -78,6 +78,11 @@ struct Plan {
     int ndim = 1;
     int64_t dims[MIFFT_MAX_DIMS] = {};
     int64_t batch = 0;
+    // mifft_plan_create_slab: the plan is one slab of a larger batch; every size-dependent choice (streaming twins, store
+    // policy, cache policy, four-step threshold) is made for THIS many transforms, so that the slab's results equal the
+    // same rows of one plan over the whole batch bit for bit.  0 = the plan's own batch.
+    int64_t sel_batch = 0;
+    double size_batch() const { return (double)(sel_batch > 0 ? sel_batch : batch); }
     int64_t prod = 1;
     int in_components = 2;
     int inverse = 0;

@@ -40,11 +40,13 @@ def all_shard_bounds(batch: int, world_size: int) -> List[Tuple[int, int]]:
 class _HipBackend:
     """Local transform through libmifft (the product path)."""
 
-    def __init__(self, in_dtype, out_dtype, in_shape, out_shape, bases, inverse, device):
+    def __init__(self, in_dtype, out_dtype, in_shape, out_shape, bases, inverse, device, whole_batch=0):
         from . import api
         self._api = api
         self.ctx = api.DeviceContext(device)
-        self.plan = api.plan_fft(in_dtype, out_dtype, in_shape, out_shape, bases=bases, inverse=inverse, ctx=self.ctx)
+        # size-dependent kernel choices follow the WHOLE batch: concatenated slabs == the single-GPU result, bit for bit
+        self.plan = api.plan_fft(in_dtype, out_dtype, in_shape, out_shape, bases=bases, inverse=inverse, ctx=self.ctx,
+                                 whole_batch=whole_batch)
 
     def run(self, out: torch.Tensor, x: torch.Tensor) -> None:
         self._api.fft(out, x, self.ctx, plan=self.plan)
@@ -54,13 +56,15 @@ class ShardedFFT:
     """One plan per rank for its slab of a ``(batch, d0.., C)`` problem.
 
     ``local_backend`` is a factory ``(in_dtype, out_dtype, in_shape, out_shape, bases, inverse)
-    -> object with .run(out, x)``; the default runs libmifft on this rank's GPU.  (The CPU test-suite
+    -> object with .run(out, x)``; the default runs libmifft on this rank's GPU.  ``match_single_gpu`` (default): the
+    slab plans make their size-dependent kernel choices for the WHOLE batch (mifft_plan_create_slab), so the concatenated
+    slabs equal the result of one plan on one GPU bit for bit; False lets every rank choose for its own slab size.  (The CPU test-suite
     injects the oracle here to exercise the sharding and the P2P plumbing over gloo.)
     """
 
     def __init__(self, in_dtype, out_dtype, in_shape: Sequence[int], out_shape: Sequence[int], *, bases=None,
                  inverse: bool = False, group=None, device: Optional[int] = None,
-                 local_backend: Optional[Callable] = None):
+                 local_backend: Optional[Callable] = None, match_single_gpu: bool = True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -77,7 +81,7 @@ class ShardedFFT:
                 if device is None:
                     device = torch.cuda.current_device()
                 self._backend = _HipBackend(in_dtype, out_dtype, self.slab_in_shape, self.slab_out_shape, bases,
-                                            inverse, device)
+                                            inverse, device, whole_batch=self.batch if match_single_gpu else 0)
             else:
                 self._backend = local_backend(in_dtype, out_dtype, self.slab_in_shape, self.slab_out_shape, bases,
                                               inverse)

@@ -121,6 +121,18 @@ int mifft_plan_create(mifft_plan** out_plan, int device, int in_dtype, int out_d
                       uint32_t flags);
 
 /*
+ * mifft_plan_create_slab -- mifft_plan_create for ONE SLAB of a batch that is split over several plans (one per GPU,
+ * SURVEY.md 8e; the reference has no counterpart: its plan always covers the whole batch, fft/fft/fft.mojo:161-210).
+ * `batch` transforms are planned and executed; every choice that depends on the tensor size (streaming / non-temporal
+ * twins, cache policy, four-step threshold) is made as for `whole_batch` transforms, so that the slab's results equal
+ * the same rows of a single plan over the whole batch BIT FOR BIT.  whole_batch = 0 is mifft_plan_create.
+ */
+int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int out_dtype,
+                           int ndim, const int64_t* dims, int64_t batch, int in_components,
+                           int inverse, const uint32_t* bases_flat, const int32_t* bases_len,
+                           uint32_t flags, int64_t whole_batch);
+
+/*
  * mifft_exec -- replaces the GPU overload of
  *   fft(output, x, ctx, *, plan)  (fft/fft/fft.mojo:262-323 ->
  *   _run_gpu_nd_fft fft/fft/_ndim_fft_gpu.mojo:462-642).

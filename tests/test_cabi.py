@@ -141,3 +141,12 @@ def test_jit_disk_cache_is_shared_between_processes(tmp_path):
     second = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
     assert second[:2] == first[:2]
     assert float(second[2]) < 0.5 * float(first[2])      # loaded, not compiled
+
+
+def test_slab_plan_rejects_a_whole_batch_smaller_than_the_slab():
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    dims = (ctypes.c_int64 * 1)(64)
+    rc = L.mifft_plan_create_slab(ctypes.byref(h), 0, 0, 0, 1, dims, 8, 2, 0, None, None, 0, 4)
+    assert rc == -9 or rc < 0 and "whole_batch" in L.mifft_last_error().decode()
+    assert not h.value

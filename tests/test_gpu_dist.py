@@ -102,3 +102,28 @@ def test_bench_single_gpu_line_carries_every_baseline_config():
     assert len(d["rfft_reference_bench"]) == 7
     for c in d["rfft_reference_bench"]:
         assert c["shape"][-1] == 1 and 0 < c["roofline_frac"] < 1 and "generic" not in c["kernels"]
+
+
+@pytest.mark.parametrize("shape,world", [((100000, 1024), 8), ((250000, 128), 4), ((30000, 1024), 3), ((10, 128, 128, 128), 8)])
+def test_slab_plans_choose_their_kernels_for_the_whole_batch(shape, world):
+    """mifft_plan_create_slab: size-dependent choices (streaming / non-temporal twins, cache policy) follow the WHOLE
+    batch, so every rank's slab equals the same rows of the single-GPU result bit for bit."""
+    import torch
+    import hackathon_fft_amd as mf
+    from hackathon_fft_amd.dist import all_shard_bounds
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(8)
+    x = torch.randn(shape + (2,), generator=g, device=dev)
+    ctx = mf.DeviceContext(0)
+    whole = mf.plan_fft(torch.float32, torch.float32, x.shape, x.shape, ctx=ctx)
+    out = torch.empty_like(x)
+    mf.fft(out, x, ctx, plan=whole)
+    names = [whole.kernel_name(d) for d in range(len(shape) - 1)]
+    for first, count in all_shard_bounds(shape[0], world):
+        xs = x[first:first + count].contiguous()
+        slab = mf.plan_fft(torch.float32, torch.float32, xs.shape, xs.shape, ctx=ctx, whole_batch=shape[0])
+        assert [slab.kernel_name(d) for d in range(len(shape) - 1)] == names
+        os_ = torch.full_like(xs, float("nan"))
+        mf.fft(os_, xs, ctx, plan=slab)
+        ctx.synchronize()
+        assert torch.equal(os_, out[first:first + count]), (shape, first, count)
