@@ -186,6 +186,41 @@ static int launch_plane_wp(const Plan& plan, const DimPass& pass, const void* in
     return MIFFT_OK;
 }
 
+// plane_kernel_wp<.., FS = true>: rows of N1 * N2 points as a four-step inside one LDS plane
+template <class CR, class CC, int PAD>
+static int launch_row2d(const Plan& plan, const DimPass& pass, const void* in, void* out, int64_t count, hipStream_t stream) {
+    if (count == 0) return MIFFT_OK;
+    using G = WavePlane<CR, CC, PAD>;
+    TileParams tp{};
+    tp.in = in;
+    tp.out = out;
+    tp.tw = pass.d_twiddle;  // W_N1 (= W_N2: square planes only)
+    tp.thi = pass.d_aux3;    // W_M, forward
+    tp.inverse = plan.inverse;
+    tp.scale = plan.inverse ? 1.0 / (double)pass.N : 1.0;
+    tp.inner = CC::TILE;
+    tp.tiles_per_outer = 1;
+    tp.n_tiles = count * pass.outer;  // rows
+    tp.reverse = 0;
+    constexpr size_t LDS = G::LDS_BYTES + (size_t)(G::N1 + G::N2) * 2 * sizeof(typename CR::T);
+    long long grid = (long long)plan.num_cus * ((160 * 1024) / (long long)LDS > 0 ? (160 * 1024) / (long long)LDS : 1);
+    if (grid > tp.n_tiles) grid = tp.n_tiles;
+    hipLaunchKernelGGL((plane_kernel_wp<CR, CC, PAD, true>), dim3((unsigned)grid), dim3(CR::THREADS), LDS, stream, tp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_error(e, "plane_kernel_wp<FS> launch");
+    return MIFFT_OK;
+}
+
+template <class CR, class CC, int PAD>
+static int prepare_row2d() {
+    using G = WavePlane<CR, CC, PAD>;
+    constexpr size_t LDS = G::LDS_BYTES + (size_t)(G::N1 + G::N2) * 2 * sizeof(typename CR::T);
+    hipError_t e = hipFuncSetAttribute((const void*)plane_kernel_wp<CR, CC, PAD, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    return MIFFT_OK;
+}
+
 template <class CR, class CC, int PAD>
 static int prepare_plane_wp() {
     using G = WavePlane<CR, CC, PAD>;
@@ -284,6 +319,28 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
         return true;
     }
     return false;
+}
+
+// 16384 = 128 x 128 points, contiguous, complex fp32 in and out: the wave-private plane kernel as a four-step inside LDS.
+// One launch, twiddles of a 128-point side + a 256-entry two-level table in LDS, against either one workgroup per
+// 128-KiB row with the 16384-entry table read from L2 in every pass (2 TB/s) or two column-tile launches (2.4 TB/s
+// effective).  MIFFT_ROW2D=0 turns it off.
+bool select_row2d(const Plan& plan, DimPass& pass) {
+    if (const char* e = getenv("MIFFT_ROW2D"))
+        if (e[0] == '0') return false;
+    if (pass.inner != 1 || !pass.first || pass.N != 16384 || plan.out_dtype != MIFFT_F32 || plan.in_dtype != MIFFT_F32 ||
+        plan.in_components != 2)
+        return false;
+    pass.kernel_name = "rows16384_fs128x128_wp";
+    pass.launch = launch_row2d<Plane128WR, Plane128WC, 8>;
+    pass.prepare = prepare_row2d<Plane128WR, Plane128WC, 8>;
+    pass.tile = 1;
+    pass.threads = 1024;
+    pass.lds_bytes = WavePlane<Plane128WR, Plane128WC, 8>::LDS_BYTES + 256 * 8;
+    pass.ld = (int)pass.N;
+    pass.N1 = 128;
+    pass.row2d_m = 16384;
+    return true;
 }
 
 bool select_fast_tstore(const Plan& plan, DimPass& pass) {

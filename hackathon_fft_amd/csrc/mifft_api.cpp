@@ -289,8 +289,10 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
     // ---- passes in execution order: last dimension first ----
     p.stage_radices = ordered;
     auto upload_twiddles = [&](DimPass& ps) -> hipError_t {
-        hipError_t e = upload_twiddle_table(out_dtype, ps.N, inverse != 0, &ps.d_twiddle);
+        // (four-step rows inside LDS: the per-side table of N1 points; the M-entry table goes to d_aux3 below)
+        hipError_t e = upload_twiddle_table(out_dtype, ps.row2d_m > 0 ? ps.N1 : ps.N, inverse != 0, &ps.d_twiddle);
         if (e == hipSuccess && ps.plane_needs_tw1) e = upload_twiddle_table(out_dtype, ps.N1, inverse != 0, &ps.d_aux);
+        if (e == hipSuccess && ps.row2d_m > 0) e = upload_twiddle_table(out_dtype, ps.row2d_m, false, &ps.d_aux3);
         if (e == hipSuccess && ps.needs_counters) {  // 16 per-launch counters + the sticky error word
             e = hipMalloc(&ps.d_aux2, 20 * sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(ps.d_aux2, 0, 20 * sizeof(unsigned));
@@ -323,6 +325,7 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
                     --i;  // dimension i-1 is covered by this pass
                 }
             }
+            if (!ok) ok = select_row2d(p, ps);  // 16384-point rows: four-step inside one LDS plane, one launch
             // Long rows of a big batched 1-D transform: two column-tile passes (four-step) move the tensor twice
             // at ~4.7 TB/s each (256 MB: 0.22 ms), which beats one workgroup per 128-KiB row (one workgroup per CU,
             // 2 TB/s: 0.26 ms) once the tensor fills the GPU in both passes; 8192-point rows are still faster in

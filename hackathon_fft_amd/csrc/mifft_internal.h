@@ -43,6 +43,7 @@ typedef int (*LaunchFn)(const Plan& plan, const DimPass& pass, const void* in, v
 struct DimPass {
     int dim_index = 0;
     int dim_index2 = -1;  // >= 0: a fused plane pass that also transforms this (next-outer) dimension
+    int64_t row2d_m = 0;  // > 0: four-step rows inside LDS (plane_kernel_wp<.., FS>): M-entry forward table in d_aux3
     int64_t N1 = 0;       // length of dim_index2
     int64_t N = 0;        // transform length
     int64_t inner = 1;    // element stride of this dim = prod(dims after it)
@@ -115,6 +116,8 @@ bool select_jit_streaming_rows(const Plan& plan, DimPass& pass, std::string& why
 // the non-temporal-store window of batched 1-D transforms (bytes moved per exec, kernels_fast.hip);
 // MIFFT_NTS_MIN_BYTES / MIFFT_NTS_MAX_BYTES are tuning knobs
 bool nts_window(const Plan& plan, double total_bytes);
+// contiguous dimension of N1 * N2 points as a four-step inside one LDS plane (kernels_fast.hip)
+bool select_row2d(const Plan& plan, DimPass& pass);
 bool nts_window_bytes(double total_bytes);  // the same window without the one-dimension condition (single-pass planes)
 bool select_jit_plane(const Plan& plan, DimPass& pass, std::string& why_not);
 // the two innermost dimensions of images that fit one XCD's L2: rows, XCD-local barrier, columns from L2

@@ -1146,7 +1146,22 @@ struct WavePlane {
     }
 };
 
-template <class CR, class CC, int PAD, int PART = 0, int NPARTS = 1>
+// work item `sub` of a wave in row pass 0 -> (row of the wave rl, butterfly b).  FS (four-step rows, see plane_kernel_wp):
+// the rows of the LDS plane are the COLUMNS of the [N2][N1] view of the transform, so adjacent lanes take adjacent rows
+// (RPW x 8-byte runs in HBM) instead of adjacent butterflies
+template <class CR, class CC, int PAD, bool FS>
+MIFFT_DEV void wp_row_item0(int sub, int& rl, int& b) {
+    using G = WavePlane<CR, CC, PAD>;
+    if constexpr (FS) {
+        rl = sub % G::RPW;
+        b = sub / G::RPW;
+    } else {
+        rl = sub / CR::NB(0);
+        b = sub - rl * CR::NB(0);
+    }
+}
+
+template <class CR, class CC, int PAD, int PART = 0, int NPARTS = 1, bool FS = false>
 MIFFT_DEV void wp_load_rows(const TileParams& p, cpx<typename CR::T> (*v)[CR::R(0)], long long base, int wave, int lane) {
     using G = WavePlane<CR, CC, PAD>;
     using V = cpx<typename CR::T>;
@@ -1155,7 +1170,16 @@ MIFFT_DEV void wp_load_rows(const TileParams& p, cpx<typename CR::T> (*v)[CR::R(
     const V* gin = (const V*)p.in;
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-        const int sub = k * 64 + lane, rl = sub / NB, b = sub - rl * NB;
+        int rl, b;
+        wp_row_item0<CR, CC, PAD, FS>(k * 64 + lane, rl, b);
+        if constexpr (FS) {  // element (row rho, column gamma) of the plane = x[gamma * N1 + rho]
+            static_assert(!FS || (same_t<typename CR::IT, T>::value && !CR::IN_REAL), "four-step rows: complex input of the plan's dtype");
+            const unsigned off = (unsigned)b * (unsigned)G::N1 + (unsigned)(wave * G::RPW + rl);
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                if ((k * R + j) % NPARTS == PART) v[k][j] = gload<(CR::NT & 1) != 0>(gin + base + (long long)j * NB * G::N1 + off);
+            continue;
+        }
         const unsigned off = (unsigned)(wave * G::RPW + rl) * (unsigned)G::N2 + (unsigned)b;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -1172,7 +1196,7 @@ MIFFT_DEV void wp_load_rows(const TileParams& p, cpx<typename CR::T> (*v)[CR::R(
     }
 }
 
-template <class CR, class CC, int PAD, int I, class Hook>
+template <class CR, class CC, int PAD, int I, class Hook, bool FS = false>
 MIFFT_DEV void wp_row_passes(const TileParams& p, cpx<typename CR::T>* lds, cpx<typename CR::T> (*pre)[CR::R(0)], int wave,
                              int lane, Hook between) {
     if constexpr (I < CR::NP) {
@@ -1184,7 +1208,14 @@ MIFFT_DEV void wp_row_passes(const TileParams& p, cpx<typename CR::T>* lds, cpx<
         V v[IPT][R];
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
-            const int sub = k * 64 + lane, rl = sub / NB, b = sub - rl * NB;
+            int rl, b;
+            if constexpr (I == 0) {
+                wp_row_item0<CR, CC, PAD, FS>(k * 64 + lane, rl, b);  // as in wp_load_rows
+            } else {
+                const int sub = k * 64 + lane;
+                rl = sub / NB;
+                b = sub - rl * NB;
+            }
             V* row = lds + (wave * G::RPW + rl) * G::PITCH;
             if constexpr (I == 0) {
 #pragma unroll
@@ -1203,21 +1234,36 @@ MIFFT_DEV void wp_row_passes(const TileParams& p, cpx<typename CR::T>* lds, cpx<
         if constexpr (I > 0) wave_lds_fence();  // this wave's reads of the exchange precede its writes below
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
-            const int sub = k * 64 + lane, rl = sub / NB, b = sub - rl * NB;
+            int rl, b;
+            if constexpr (I == 0) {
+                wp_row_item0<CR, CC, PAD, FS>(k * 64 + lane, rl, b);
+            } else {
+                const int sub = k * 64 + lane;
+                rl = sub / NB;
+                b = sub - rl * NB;
+            }
             V* row = lds + (wave * G::RPW + rl) * G::PITCH;
             Dft<R, T, 1>::run(v[k]);
             const int q = b / P, pp = b - q * P, o0 = q * P * R + pp;
 #pragma unroll
             for (int s = 0; s < R; ++s) {
-                if constexpr (I == CR::NP - 1)
+                if constexpr (I == CR::NP - 1) {
+                    if constexpr (FS) {
+                        // four-step twiddle between the two sides: W_M^(rho * kappa), M = N1 * N2, from the two-level
+                        // table behind the plane (lo: W_M^l, l < N2; hi: W_M^(N2 h) = W_N1^h, h < N1)
+                        const V* fs = lds + G::LDS_BYTES / sizeof(V);
+                        const int m = (wave * G::RPW + rl) * (o0 + s * P);
+                        v[k][s] = cmul(v[k][s], cmul(fs[m % G::N2], fs[G::N2 + m / G::N2]));
+                    }
                     row[o0 + s * P] = v[k][s];  // hand-over layout: natural order
-                else
+                } else {
                     row[swz<CR, I>(o0 + s * P)] = v[k][s];
+                }
             }
         }
         wave_lds_fence();
         if constexpr (I == 0) between(IntC<1>{});
-        wp_row_passes<CR, CC, PAD, I + 1>(p, lds, pre, wave, lane, between);
+        wp_row_passes<CR, CC, PAD, I + 1, Hook, FS>(p, lds, pre, wave, lane, between);
     }
 }
 
@@ -1281,7 +1327,13 @@ MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long
     }
 }
 
-template <class CR, class CC, int PAD>
+// FS = true: the same kernel as a ONE-DIMENSIONAL transform of M = N1 * N2 points per "plane" (four-step inside LDS):
+//   X[N2 kr + kc] = sum_rho W_N1^(rho kr) * W_M^(rho kc) * [ sum_gamma x[N1 gamma + rho] W_N2^(gamma kc) ]
+// i.e. row rho of the plane holds x[N1 gamma + rho] (the loads transpose: adjacent lanes take adjacent rows), the row side
+// transforms over gamma, its last pass multiplies by W_M^(rho kc), the column side transforms over rho and stores the
+// result in natural order.  Twiddles of one 128-point side + a two-level table of N1 + N2 entries replace the M-entry
+// table a one-row-per-workgroup tile kernel reads from L2 in every pass (p.thi = the M-entry table W_M^m, forward).
+template <class CR, class CC, int PAD, bool FS = false>
 __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const TileParams p) {
     using G = WavePlane<CR, CC, PAD>;
     using T = typename CR::T;
@@ -1290,8 +1342,10 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const T
     static_assert(CR::THREADS == CC::THREADS && CR::TWMODE == TW_LDS && CC::TWMODE == TW_LDS, "one thread count, LDS twiddles");
     static_assert(G::exact(), "every pass must be an exact number of wave rounds over wave-owned rows / columns");
     static_assert(G::LDS_BYTES <= 160 * 1024, "plane + twiddle tables must fit LDS");
+    constexpr size_t FS_BYTES = FS ? (size_t)(G::N1 + G::N2) * sizeof(V) : 0;  // two-level four-step table behind the plane
+    static_assert(G::LDS_BYTES + FS_BYTES <= 160 * 1024 && G::LDS_BYTES % sizeof(V) == 0, "four-step table must fit too");
 #ifdef MIFFT_STATIC_LDS
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES + FS_BYTES];
 #else
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #endif
@@ -1299,13 +1353,18 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const T
     const int tid0 = threadIdx.x;
     fill_lds_tw<CR, 1>(lds + G::DATA, (const V*)p.tw, tid0, p.inverse);
     if constexpr (!G::SHARED_TW) fill_lds_tw<CC, 1>(lds + G::DATA + G::CSHIFT, (const V*)p.tlo, tid0, p.inverse);
+    if constexpr (FS) {
+        V* fs = lds + G::LDS_BYTES / sizeof(V);
+        const V* wm = (const V*)p.thi;
+        for (int e = tid0; e < G::N2 + G::N1; e += CR::THREADS) fs[e] = e < G::N2 ? wm[e] : wm[(e - G::N2) * G::N2];
+    }
     __syncthreads();
 
     constexpr long long PLANE = (long long)G::N1 * G::N2;
     MIFFT_STAMP(G, -1);
     V pre[G::RIPT(0)][CR::R(0)];
     long long t = blockIdx.x;
-    if (t < p.n_tiles) wp_load_rows<CR, CC, PAD>(p, pre, tile_id(p, t) * PLANE, tid0 >> 6, tid0 & 63);
+    if (t < p.n_tiles) wp_load_rows<CR, CC, PAD, 0, 1, FS>(p, pre, tile_id(p, t) * PLANE, tid0 >> 6, tid0 & 63);
     for (; t < p.n_tiles; t += gridDim.x) {
         int tid = tid0;  // opaque per plane: offsets are re-derived instead of being hoisted and kept live (tile_kernel)
 #ifndef MIFFT_NO_OPAQUE_TID
@@ -1323,25 +1382,25 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const T
         // behind the first column exchange (see run_pass: a burst of loads stalls every wave in its issue)
         constexpr int SLICES = (CR::PREFETCH && MIFFT_SLICED_PREFETCH_PLANE) ? 4 : 1;
         const long long nbase = tn < p.n_tiles ? tile_id(p, tn) * PLANE : 0;
-        if (CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD, 0, SLICES>(p, pre, nbase, wave, lane);
+        if (CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD, 0, SLICES, FS>(p, pre, nbase, wave, lane);
         auto slice = [&](auto kc) {
             constexpr int K = decltype(kc)::value;
             if constexpr (CR::PREFETCH && SLICES > 1 && K >= 1 && K < SLICES) {
-                if (tn < p.n_tiles) wp_load_rows<CR, CC, PAD, K, SLICES>(p, pre, nbase, wave, lane);
+                if (tn < p.n_tiles) wp_load_rows<CR, CC, PAD, K, SLICES, FS>(p, pre, nbase, wave, lane);
             }
         };
         auto drain = [&]() {  // ahead of this plane's HBM stores (tile_kernel / run_pass)
             if constexpr (CR::PREFETCH) vm_drain();
         };
         MIFFT_STAMP(G, 0);  // plane bookkeeping, take-over of the prefetched registers, first slice of the next loads
-        wp_row_passes<CR, CC, PAD, 0>(p, lds, cur, wave, lane, slice);
+        wp_row_passes<CR, CC, PAD, 0, decltype(slice), FS>(p, lds, cur, wave, lane, slice);
         MIFFT_STAMP(G, 1);  // row passes (wave-private)
         __syncthreads();  // hand-over: every row is complete before any column starts
         MIFFT_STAMP(G, 2);  // hand-over barrier
         slice(IntC<2>{});
         wp_col_passes<CR, CC, PAD, 0>(p, lds, base, wave, lane, drain, slice);
         MIFFT_STAMP(G, 3);  // column passes incl. the barrier behind the last gather and the HBM stores
-        if (!CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD>(p, pre, tile_id(p, tn) * PLANE, wave, lane);
+        if (!CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD, 0, 1, FS>(p, pre, tile_id(p, tn) * PLANE, wave, lane);
     }
     MIFFT_STAMP_DUMP(G, p);
 }
