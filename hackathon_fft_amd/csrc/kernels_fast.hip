@@ -194,7 +194,8 @@ static int launch_row2d(const Plan& plan, const DimPass& pass, const void* in, v
     TileParams tp{};
     tp.in = in;
     tp.out = out;
-    tp.tw = pass.d_twiddle;  // W_N1 (= W_N2: square planes only)
+    tp.tw = pass.d_twiddle;  // row side, W_N2
+    tp.tlo = pass.d_aux;     // column side, W_N1 (rectangular planes)
     tp.thi = pass.d_aux3;    // W_M, forward
     tp.inverse = plan.inverse;
     tp.scale = plan.inverse ? 1.0 / (double)pass.N : 1.0;
@@ -321,26 +322,50 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
     return false;
 }
 
-// 16384 = 128 x 128 points, contiguous, complex fp32 in and out: the wave-private plane kernel as a four-step inside LDS.
-// One launch, twiddles of a 128-point side + a 256-entry two-level table in LDS, against either one workgroup per
-// 128-KiB row with the 16384-entry table read from L2 in every pass (2 TB/s) or two column-tile launches (2.4 TB/s
-// effective).  MIFFT_ROW2D=0 turns it off.
+// Long contiguous dimensions as a four-step INSIDE one LDS plane (plane_kernel_wp<.., FS>): 16384 = 128 x 128 and 8192 = 64
+// rows x 128 columns, complex fp32 in and out.  One launch, twiddles of the two short sides + a two-level table of N1 + N2
+// entries in LDS, against one workgroup per row reading a length-M table in every pass (16384: global table, 2 TB/s;
+// 8192: 64 KB of LDS for the table, one workgroup per CU, 4 TB/s) or two column-tile launches for big batches (2.4 TB/s
+// effective).  3906 x 16384 0.385 -> 0.246 ms, 100 x 16384 0.0241 -> 0.0167 ms.  MIFFT_ROW2D=0 turns it off.
+using Row2D64R = TileCfg<float, 128, 2, 8, 16, 1, 1, 64, 512, false, true, false, TW_LDS, 2, true>;
+using Row2D64C = TileCfg<float, 64, 2, 8, 8, 1, 1, 128, 512, true, false, true, TW_LDS, 2, false>;
+
+struct Row2DEntry {
+    int64_t M;
+    int N1;  // rows of the plane = column-side length
+    const char* name;
+    LaunchFn launch;
+    int (*prepare)();
+    int threads;
+    size_t lds;
+};
+static const Row2DEntry kRow2DTable[] = {
+    {16384, 128, "rows16384_fs128x128_wp", launch_row2d<Plane128WR, Plane128WC, 8>, prepare_row2d<Plane128WR, Plane128WC, 8>,
+     1024, WavePlane<Plane128WR, Plane128WC, 8>::LDS_BYTES + 256 * 8},
+    {8192, 64, "rows8192_fs64x128_wp", launch_row2d<Row2D64R, Row2D64C, 8>, prepare_row2d<Row2D64R, Row2D64C, 8>, 512,
+     WavePlane<Row2D64R, Row2D64C, 8>::LDS_BYTES + 192 * 8},
+};
+
 bool select_row2d(const Plan& plan, DimPass& pass) {
     if (const char* e = getenv("MIFFT_ROW2D"))
         if (e[0] == '0') return false;
-    if (pass.inner != 1 || !pass.first || pass.N != 16384 || plan.out_dtype != MIFFT_F32 || plan.in_dtype != MIFFT_F32 ||
-        plan.in_components != 2)
+    if (pass.inner != 1 || !pass.first || plan.out_dtype != MIFFT_F32 || plan.in_dtype != MIFFT_F32 || plan.in_components != 2)
         return false;
-    pass.kernel_name = "rows16384_fs128x128_wp";
-    pass.launch = launch_row2d<Plane128WR, Plane128WC, 8>;
-    pass.prepare = prepare_row2d<Plane128WR, Plane128WC, 8>;
-    pass.tile = 1;
-    pass.threads = 1024;
-    pass.lds_bytes = WavePlane<Plane128WR, Plane128WC, 8>::LDS_BYTES + 256 * 8;
-    pass.ld = (int)pass.N;
-    pass.N1 = 128;
-    pass.row2d_m = 16384;
-    return true;
+    for (const Row2DEntry& e : kRow2DTable) {
+        if (e.M != pass.N) continue;
+        pass.kernel_name = e.name;
+        pass.launch = e.launch;
+        pass.prepare = e.prepare;
+        pass.tile = 1;
+        pass.threads = e.threads;
+        pass.lds_bytes = e.lds;
+        pass.ld = (int)pass.N;
+        pass.N1 = e.N1;
+        pass.row2d_m = e.M;
+        pass.plane_needs_tw1 = (int64_t)e.N1 * e.N1 != e.M;  // rectangular: the column side has its own table (d_aux)
+        return true;
+    }
+    return false;
 }
 
 bool select_fast_tstore(const Plan& plan, DimPass& pass) {

@@ -289,8 +289,9 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
     // ---- passes in execution order: last dimension first ----
     p.stage_radices = ordered;
     auto upload_twiddles = [&](DimPass& ps) -> hipError_t {
-        // (four-step rows inside LDS: the per-side table of N1 points; the M-entry table goes to d_aux3 below)
-        hipError_t e = upload_twiddle_table(out_dtype, ps.row2d_m > 0 ? ps.N1 : ps.N, inverse != 0, &ps.d_twiddle);
+        // (four-step rows inside LDS: the table of the row side, M / N1 points; the column side's goes to d_aux when it
+        //  differs, the M-entry table to d_aux3)
+        hipError_t e = upload_twiddle_table(out_dtype, ps.row2d_m > 0 ? ps.row2d_m / ps.N1 : ps.N, inverse != 0, &ps.d_twiddle);
         if (e == hipSuccess && ps.plane_needs_tw1) e = upload_twiddle_table(out_dtype, ps.N1, inverse != 0, &ps.d_aux);
         if (e == hipSuccess && ps.row2d_m > 0) e = upload_twiddle_table(out_dtype, ps.row2d_m, false, &ps.d_aux3);
         if (e == hipSuccess && ps.needs_counters) {  // 16 per-launch counters + the sticky error word

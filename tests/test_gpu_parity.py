@@ -420,6 +420,27 @@ def test_full_size_real_input(shape):
         assert rel_l2(got[i:i + 1], ref[i:i + 1]) < REL_L2_TOL_F32, (shape, idx[i])
 
 
+@pytest.mark.parametrize("shape", [(3, 16384), (1, 8192), (261, 16384), (515, 8192), (2, 3, 16384), (5, 2, 8192)])
+def test_long_rows_as_a_four_step_inside_lds(shape):
+    """plane_kernel_wp<FS>: 16384 = 128 x 128 and 8192 = 64 x 128 points per row in one launch"""
+    rng = np.random.default_rng(shape[0] + shape[-1])
+    x = rng.standard_normal(shape + (2,)).astype(np.float32)
+    out, plan = gpu_fft(x, out_dtype=np.float32)
+    assert "_fs" in plan.kernel_name(len(shape) - 2) and "_wp" in plan.kernel_name(len(shape) - 2), plan.kernel_name(len(shape) - 2)
+    assert not np.isnan(out).any()
+    xc = x[..., 0].astype(np.float64) + 1j * x[..., 1].astype(np.float64)
+    truth = np.fft.fftn(xc, axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
+    sel = [0, shape[0] - 1]
+    assert rel_l2(out[sel], O.fftn(x[sel], out_dtype=np.float32)) < REL_L2_TOL_F32   # the oracle on the first and last transform
+    back, _ = gpu_fft(out, inverse=True, out_dtype=np.float32)
+    assert rel_l2(back, x) < REL_L2_TOL_F32
+    # ragged ranges of the batch through the same plan
+    if shape[0] > 4:
+        part, _ = gpu_fft(x, out_dtype=np.float32, first=2, count=shape[0] - 3)
+        assert np.array_equal(part[2:shape[0] - 1], out[2:shape[0] - 1]) and np.isnan(part[:2]).all() and np.isnan(part[-1:]).all()
+
+
 # batches in the 0.25-0.55 GB window take the non-temporal-store twins (DESIGN 3.1c): table, generated table,
 # runtime-specialised lengths, fp64, and planes that are a 2-D plan's only pass
 WINDOW_CASES = [((250000, 93), torch.float32), ((250000, 128), torch.float32), ((30000, 1024), torch.float32),
@@ -509,9 +530,12 @@ def test_four_step_large_dimension(n, batch, dtype):
     x = rng.standard_normal((batch, n, 2)).astype(dtype)
     out, plan = gpu_fft(x, out_dtype=dtype)
     assert not np.isnan(out).any()
-    assert plan.num_launches == (2 if "_ts" in plan.kernel_name(0) else 3)
-    if dtype == np.float32 and n & (n - 1) == 0:
-        assert plan.num_launches == 2
+    if "_fs" in plan.kernel_name(0):   # 16384 points: the four-step runs inside one LDS plane, one launch
+        assert plan.num_launches == 1 and n == 16384
+    else:
+        assert plan.num_launches == (2 if "_ts" in plan.kernel_name(0) else 3)
+        if dtype == np.float32 and n & (n - 1) == 0:
+            assert plan.num_launches == 2
     truth = np.fft.fft(to_complex(x), axis=1)
     tol = REL_L2_TOL_F32 if dtype == np.float32 else 1e-11
     assert rel_l2(out, from_complex(truth, np.float64)) < tol
