@@ -331,6 +331,7 @@ using Row2D64R = TileCfg<float, 128, 2, 8, 16, 1, 1, 64, 512, false, true, false
 using Row2D64C = TileCfg<float, 64, 2, 8, 8, 1, 1, 128, 512, true, false, true, TW_LDS, 2, false>;
 
 struct Row2DEntry {
+    bool in_real;
     int64_t M;
     int N1;  // rows of the plane = column-side length
     const char* name;
@@ -340,19 +341,21 @@ struct Row2DEntry {
     size_t lds;
 };
 static const Row2DEntry kRow2DTable[] = {
-    {16384, 128, "rows16384_fs128x128_wp", launch_row2d<Plane128WR, Plane128WC, 8>, prepare_row2d<Plane128WR, Plane128WC, 8>,
+    {false, 16384, 128, "rows16384_fs128x128_wp", launch_row2d<Plane128WR, Plane128WC, 8>, prepare_row2d<Plane128WR, Plane128WC, 8>,
      1024, WavePlane<Plane128WR, Plane128WC, 8>::LDS_BYTES + 256 * 8},
-    {8192, 64, "rows8192_fs64x128_wp", launch_row2d<Row2D64R, Row2D64C, 8>, prepare_row2d<Row2D64R, Row2D64C, 8>, 512,
+    {false, 8192, 64, "rows8192_fs64x128_wp", launch_row2d<Row2D64R, Row2D64C, 8>, prepare_row2d<Row2D64R, Row2D64C, 8>, 512,
      WavePlane<Row2D64R, Row2D64C, 8>::LDS_BYTES + 192 * 8},
+    {true, 16384, 128, "rows16384_fs128x128_wp_r", launch_row2d<Plane128WRR, Plane128WC, 8>, prepare_row2d<Plane128WRR, Plane128WC, 8>,
+     1024, WavePlane<Plane128WRR, Plane128WC, 8>::LDS_BYTES + 256 * 8},
+    // (real input at 8192 points loses 10-19 % against the runtime-specialised row kernel: 32-byte runs on the load side)
 };
 
 bool select_row2d(const Plan& plan, DimPass& pass) {
     if (const char* e = getenv("MIFFT_ROW2D"))
         if (e[0] == '0') return false;
-    if (pass.inner != 1 || !pass.first || plan.out_dtype != MIFFT_F32 || plan.in_dtype != MIFFT_F32 || plan.in_components != 2)
-        return false;
+    if (pass.inner != 1 || !pass.first || plan.out_dtype != MIFFT_F32 || plan.in_dtype != MIFFT_F32) return false;
     for (const Row2DEntry& e : kRow2DTable) {
-        if (e.M != pass.N) continue;
+        if (e.M != pass.N || e.in_real != (plan.in_components == 1)) continue;
         pass.kernel_name = e.name;
         pass.launch = e.launch;
         pass.prepare = e.prepare;

@@ -1173,11 +1173,18 @@ MIFFT_DEV void wp_load_rows(const TileParams& p, cpx<typename CR::T> (*v)[CR::R(
         int rl, b;
         wp_row_item0<CR, CC, PAD, FS>(k * 64 + lane, rl, b);
         if constexpr (FS) {  // element (row rho, column gamma) of the plane = x[gamma * N1 + rho]
-            static_assert(!FS || (same_t<typename CR::IT, T>::value && !CR::IN_REAL), "four-step rows: complex input of the plan's dtype");
+            static_assert(!FS || same_t<typename CR::IT, T>::value, "four-step rows: input of the plan's dtype");
             const unsigned off = (unsigned)b * (unsigned)G::N1 + (unsigned)(wave * G::RPW + rl);
 #pragma unroll
-            for (int j = 0; j < R; ++j)
-                if ((k * R + j) % NPARTS == PART) v[k][j] = gload<(CR::NT & 1) != 0>(gin + base + (long long)j * NB * G::N1 + off);
+            for (int j = 0; j < R; ++j) {
+                if ((k * R + j) % NPARTS != PART) continue;
+                if constexpr (CR::IN_REAL) {
+                    v[k][j].x = gload_real<(CR::NT & 1) != 0>((const T*)p.in + base + (long long)j * NB * G::N1 + off);
+                    v[k][j].y = (T)0;
+                } else {
+                    v[k][j] = gload<(CR::NT & 1) != 0>(gin + base + (long long)j * NB * G::N1 + off);
+                }
+            }
             continue;
         }
         const unsigned off = (unsigned)(wave * G::RPW + rl) * (unsigned)G::N2 + (unsigned)b;
