@@ -345,6 +345,7 @@ static const Row2DEntry kRow2DTable[] = {
      1024, WavePlane<Plane128WR, Plane128WC, 8>::LDS_BYTES + 256 * 8},
     {false, 8192, 64, "rows8192_fs64x128_wp", launch_row2d<Row2D64R, Row2D64C, 8>, prepare_row2d<Row2D64R, Row2D64C, 8>, 512,
      WavePlane<Row2D64R, Row2D64C, 8>::LDS_BYTES + 192 * 8},
+    // (4096 = 64 x 64 measured too: 4.8 TB/s at 50k rows against 5.4 for the four-pass row kernel -- not taken)
     {true, 16384, 128, "rows16384_fs128x128_wp_r", launch_row2d<Plane128WRR, Plane128WC, 8>, prepare_row2d<Plane128WRR, Plane128WC, 8>,
      1024, WavePlane<Plane128WRR, Plane128WC, 8>::LDS_BYTES + 256 * 8},
     // (real input at 8192 points loses 10-19 % against the runtime-specialised row kernel: 32-byte runs on the load side)
