@@ -330,7 +330,11 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
 using Row2D64R = TileCfg<float, 128, 2, 8, 16, 1, 1, 64, 512, false, true, false, TW_LDS, 2, true>;
 using Row2D64C = TileCfg<float, 64, 2, 8, 8, 1, 1, 128, 512, true, false, true, TW_LDS, 2, false>;
 
+using Row2D64RD = TileCfg<double, 128, 2, 8, 16, 1, 1, 64, 512, false, true, false, TW_LDS, 1, true>;
+using Row2D64CD = TileCfg<double, 64, 2, 8, 8, 1, 1, 128, 512, true, false, true, TW_LDS, 1, false>;
+
 struct Row2DEntry {
+    int dtype;
     bool in_real;
     int64_t M;
     int N1;  // rows of the plane = column-side length
@@ -341,12 +345,14 @@ struct Row2DEntry {
     size_t lds;
 };
 static const Row2DEntry kRow2DTable[] = {
-    {false, 16384, 128, "rows16384_fs128x128_wp", launch_row2d<Plane128WR, Plane128WC, 8>, prepare_row2d<Plane128WR, Plane128WC, 8>,
+    {MIFFT_F32, false, 16384, 128, "rows16384_fs128x128_wp", launch_row2d<Plane128WR, Plane128WC, 8>, prepare_row2d<Plane128WR, Plane128WC, 8>,
      1024, WavePlane<Plane128WR, Plane128WC, 8>::LDS_BYTES + 256 * 8},
-    {false, 8192, 64, "rows8192_fs64x128_wp", launch_row2d<Row2D64R, Row2D64C, 8>, prepare_row2d<Row2D64R, Row2D64C, 8>, 512,
+    {MIFFT_F32, false, 8192, 64, "rows8192_fs64x128_wp", launch_row2d<Row2D64R, Row2D64C, 8>, prepare_row2d<Row2D64R, Row2D64C, 8>, 512,
      WavePlane<Row2D64R, Row2D64C, 8>::LDS_BYTES + 192 * 8},
     // (4096 = 64 x 64 measured too: 4.8 TB/s at 50k rows against 5.4 for the four-pass row kernel -- not taken)
-    {true, 16384, 128, "rows16384_fs128x128_wp_r", launch_row2d<Plane128WRR, Plane128WC, 8>, prepare_row2d<Plane128WRR, Plane128WC, 8>,
+    {MIFFT_F64, false, 8192, 64, "rows8192_f64_fs64x128_wp", launch_row2d<Row2D64RD, Row2D64CD, 4>, prepare_row2d<Row2D64RD, Row2D64CD, 4>,
+     512, WavePlane<Row2D64RD, Row2D64CD, 4>::LDS_BYTES + 192 * 16},
+    {MIFFT_F32, true, 16384, 128, "rows16384_fs128x128_wp_r", launch_row2d<Plane128WRR, Plane128WC, 8>, prepare_row2d<Plane128WRR, Plane128WC, 8>,
      1024, WavePlane<Plane128WRR, Plane128WC, 8>::LDS_BYTES + 256 * 8},
     // (real input at 8192 points loses 10-19 % against the runtime-specialised row kernel: 32-byte runs on the load side)
 };
@@ -354,9 +360,9 @@ static const Row2DEntry kRow2DTable[] = {
 bool select_row2d(const Plan& plan, DimPass& pass) {
     if (const char* e = getenv("MIFFT_ROW2D"))
         if (e[0] == '0') return false;
-    if (pass.inner != 1 || !pass.first || plan.out_dtype != MIFFT_F32 || plan.in_dtype != MIFFT_F32) return false;
+    if (pass.inner != 1 || !pass.first || plan.in_dtype != plan.out_dtype) return false;
     for (const Row2DEntry& e : kRow2DTable) {
-        if (e.M != pass.N || e.in_real != (plan.in_components == 1)) continue;
+        if (e.M != pass.N || e.dtype != plan.out_dtype || e.in_real != (plan.in_components == 1)) continue;
         pass.kernel_name = e.name;
         pass.launch = e.launch;
         pass.prepare = e.prepare;

@@ -442,6 +442,19 @@ def test_long_rows_as_a_four_step_inside_lds(shape, comps):
         assert np.array_equal(part[2:shape[0] - 1], out[2:shape[0] - 1]) and np.isnan(part[:2]).all() and np.isnan(part[-1:]).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 8192), (133, 8192), (3, 2, 8192)])
+def test_long_fp64_rows_as_a_four_step_inside_lds(shape):
+    rng = np.random.default_rng(shape[0])
+    x = rng.standard_normal(shape + (2,))
+    out, plan = gpu_fft(x, out_dtype=np.float64)
+    assert "_fs" in plan.kernel_name(len(shape) - 2), plan.kernel_name(len(shape) - 2)
+    truth = np.fft.fftn(x[..., 0] + 1j * x[..., 1], axes=tuple(range(1, len(shape))))
+    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F64
+    assert rel_l2(out[:1], O.fftn(x[:1], out_dtype=np.float64)) < REL_L2_TOL_F64
+    back, _ = gpu_fft(out, inverse=True, out_dtype=np.float64)
+    assert rel_l2(back, x) < REL_L2_TOL_F64
+
+
 # batches in the 0.25-0.55 GB window take the non-temporal-store twins: table, generated table,
 # runtime-specialised lengths, fp64, and planes that are a 2-D plan's only pass
 WINDOW_CASES = [((250000, 93), torch.float32), ((250000, 128), torch.float32), ((30000, 1024), torch.float32),
