@@ -109,7 +109,7 @@ def test_planes_are_fused(shape, dtype, comps):
         assert rel_l2(back, x) < tol
 
 
-@pytest.mark.parametrize("n,dtype", [(4984, np.float64), (6000, np.float64), (8192, np.float64), (10000, np.float32),
+@pytest.mark.parametrize("n,dtype", [(4984, np.float64), (6000, np.float64), (7168, np.float64), (10000, np.float32),
                                      (15625, np.float32), (12000, np.float32)])
 def test_long_rows_one_per_workgroup(n, dtype):
     """Rows of up to 128 KiB (16384 points fp32, 8192 fp64) without a table entry: one row per workgroup, twiddles
