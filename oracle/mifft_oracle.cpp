@@ -17,7 +17,8 @@
 // `sin` (mojo 0.26.3.0.dev2026032521, fft/pixi.lock:168-176) -- restated here
 // as four real FMAs and libm cos/sin.
 //
-// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -fopenmp).
+// Build: see oracle/Makefile (g++ -O3 -march=x86-64-v3 -ffp-contract=off -fopenmp: std::fma becomes the hardware
+// instruction instead of a libm call; contraction stays off, so FMAs appear exactly where the reference writes .fma()).
 
 #include <algorithm>
 #include <cmath>
@@ -26,6 +27,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #ifdef _OPENMP
@@ -286,6 +288,9 @@ struct DimPlan {
     std::vector<std::vector<int32_t>> src_n;   // [stage][i]            fft/fft/_fft.mojo:233-235
     std::vector<std::vector<int32_t>> tw_idx;  // [stage][(j-1)*N + i]  fft/fft/_fft.mojo:264-267
     std::vector<std::vector<uint8_t>> kind;    // small only
+    // large N only: the stage's twiddles laid out [(j-1)][t], t = s*P + p = i % (P*R) -- the same values tw[tw_idx] reads,
+    // contiguous along p so that the p loop of run_stage_rows vectorises
+    std::vector<std::vector<Cx<T>>> tw_seq;
 };
 
 struct OraclePlan {
@@ -314,6 +319,7 @@ static void build_dimplan(DimPlan<T>& dp, int64_t N, const std::vector<uint64_t>
     dp.src_n.resize(S);
     dp.tw_idx.resize(S);
     dp.kind.resize(S);
+    dp.tw_seq.resize(S);
     for (size_t b = 0; b < S; ++b) {
         const int64_t R = (int64_t)ordered[b], P = (int64_t)processed[b];
         const int64_t next_offset = P * R, ratio = N / next_offset;
@@ -328,6 +334,11 @@ static void build_dimplan(DimPlan<T>& dp, int64_t N, const std::vector<uint64_t>
                 dp.tw_idx[b][(j - 1) * N + i] = (int32_t)twf_index;
                 if (dp.small) dp.kind[b][(j - 1) * N + i] = classify(dp.tw[twf_index]);
             }
+        }
+        if (!dp.small) {
+            dp.tw_seq[b].resize((R - 1) * next_offset);
+            for (int64_t j = 1; j < R; ++j)
+                for (int64_t t = 0; t < next_offset; ++t) dp.tw_seq[b][(j - 1) * next_offset + t] = dp.tw[dp.tw_idx[b][(j - 1) * N + t]];
         }
     }
 }
@@ -379,10 +390,48 @@ static void run_stage_impl(const DimPlan<T>& dp, size_t b, Cx<T>* dst, const TIn
     }
 }
 
+// The large-N stage (MODE 0) on complex input of the working dtype, walked as q / s / p with p innermost: output
+// i = q*P*R + s*P + p reads src[q*P + p + j*N/R] and the twiddle of t = s*P + p -- everything contiguous along p, which is
+// how the reference's unrolled scalar loop (fft/fft/_ndim_fft_cpu.mojo:212-241, `vectorize[1, unroll_factor=width]` over
+// local_i) ends up being scheduled.  Per output element the operations and their order are those of run_stage_impl
+// (acc = x_0; acc = w_j.fma(x_j, acc) for j = 1..R-1; optional 1/N), so results are bit-identical; only the loop nest
+// differs.
+template <typename T>
+static void run_stage_rows(const DimPlan<T>& dp, size_t b, Cx<T>* __restrict dst, const Cx<T>* __restrict src, bool inverse) {
+    const int64_t N = dp.N, R = (int64_t)dp.radices[b], P = (int64_t)dp.processed[b];
+    const int64_t step = N / R, PR = P * R;
+    const bool last_inverse = inverse && PR == N;
+    const T inv_n = (T)(1.0 / (double)N);
+    const Cx<T>* __restrict tws = dp.tw_seq[b].data();
+    for (int64_t q = 0; q < N / PR; ++q) {
+        for (int64_t s = 0; s < R; ++s) {
+            Cx<T>* __restrict d = dst + q * PR + s * P;
+            const Cx<T>* __restrict x0 = src + q * P;
+            for (int64_t p = 0; p < P; ++p) d[p] = x0[p];
+            for (int64_t j = 1; j < R; ++j) {
+                const Cx<T>* __restrict xj = x0 + j * step;
+                const Cx<T>* __restrict w = tws + (j - 1) * PR + s * P;
+                for (int64_t p = 0; p < P; ++p) d[p] = cfma(w[p], xj[p], d[p]);  // _fft.mojo:290
+            }
+            if (last_inverse)
+                for (int64_t p = 0; p < P; ++p) {
+                    d[p].re *= inv_n;
+                    d[p].im *= inv_n;
+                }
+        }
+    }
+}
+
 template <typename T, typename TIn>
 static void run_stage(const DimPlan<T>& dp, size_t b, Cx<T>* dst, const TIn* src, int comps,
                       bool do_rfft, bool inverse) {
     const int mode = !dp.small ? 0 : (do_rfft ? 2 : 1);
+    if constexpr (std::is_same<T, TIn>::value) {
+        if (mode == 0 && comps == 2 && dp.processed[b] >= 8) {  // (shorter runs of p: the per-element loop below)
+            run_stage_rows<T>(dp, b, dst, (const Cx<T>*)src, inverse);
+            return;
+        }
+    }
     if (comps == 1) {
         if (mode == 0) run_stage_impl<T, TIn, 1, 0>(dp, b, dst, src, inverse);
         else if (mode == 1) run_stage_impl<T, TIn, 1, 1>(dp, b, dst, src, inverse);
