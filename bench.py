@@ -19,11 +19,14 @@ the ranks.  Either way WORLD_SIZE must equal --gpus, and `ranks_seen` (an all-re
 The default run also carries the strong-scaling leg as the object `strong_config5`.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline       HBM roofline of the dominant kernel; `achieved` = algorithmic bytes per launch (16 B per complex element:
-                 one 8-B read + one 8-B write) / the average launch duration measured with HIP events on
-                 the launch stream inside libmifft (mifft_time_exec); `traffic` = HBM bytes per step from `rocprofv3
-                 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` child passes of this command, run by this process BEFORE it
-                 touches the GPU (N=1 default run; else the committed profile of the same command)
+  roofline       HBM roofline of the dominant kernel; `achieved` / `frac` = algorithmic bytes per launch (16 B per complex
+                 element: one 8-B read + one 8-B write) / ms_per_step of the K TIMED STEPS; the same
+                 figure from HIP events on the launch stream inside libmifft (mifft_time_exec, a separate loop right
+                 after the timed steps) is `frac_hip_events`; `traffic` = HBM bytes per step from `rocprofv3 --pmc
+                 FETCH_SIZE` / `--pmc WRITE_SIZE` child passes of this command, run by this process BEFORE it touches
+                 the GPU (N=1 default run; else the committed profile of the same command); `copy` = COPY kernels with
+                 the tile shapes and cache policy of the FFT passes moving the same bytes in this run on this box
+                 (tools/libmifft_probe.so: what the chip gives a kernel that only moves the pass's bytes)
   ramp           the untimed clock / cache ramp that precedes the W warm-up steps (ms, execs)
   configs        (N=1) the other four BASELINE.json configs, each timed the same way in this run
   rfft_reference_bench  (N=1) the shapes of the reference's own GPU benchmark in ITS mode: real input, full complex
@@ -160,7 +163,8 @@ def cpu_baseline(shape, bases, budget_s=12.0):
     res = {
         "value": round(gflops(b1, t1), 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
         "sample": f"{b1} of {shape[0]} leading-batch entries of the same shape, all {cores} host threads, "
-                  f"oracle/libmifft_oracle.so (C++ restatement of the reference CPU path), {t1 * 1e3:.1f} ms",
+                  f"oracle/libmifft_oracle.so (C++ restatement of the reference CPU path; g++ -O3 -march=x86-64-v3 "
+                  f"-ffp-contract=off -fopenmp), nproc={os.cpu_count()}, {t1 * 1e3:.1f} ms",
         "ms_per_transform": round(t1 * 1e3 / b1, 6),
     }
     # one thread (README.md:102-110): a sample sized to about a sixth of the budget
@@ -196,6 +200,74 @@ def cpu_baseline(shape, bases, budget_s=12.0):
     except Exception as e:  # a missing comparator must not cost the bench line
         res["comparators_error"] = repr(e)
     return res
+
+
+_PROBE = None
+
+
+def probe_lib():
+    """tools/libmifft_probe.so (copy kernels, measurement tooling); None when it is not built."""
+    global _PROBE
+    if _PROBE is None:
+        import ctypes
+        path = os.path.join(ROOT, "tools", "libmifft_probe.so")
+        if not os.path.exists(path):
+            _PROBE = False
+        else:
+            L = ctypes.CDLL(path)
+            L.probe_copy_flat.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+            L.probe_copy_cols.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.POINTER(ctypes.c_float)]
+            _PROBE = L
+    return _PROBE or None
+
+
+def copy_ceiling(name, kernels, x, out, iters=30):
+    """COPY kernels shaped like the passes of workload `name` (complex64 only), timed with HIP events on the current
+    stream right after the FFT's timed steps: [{pass, ms}] or None.  1-D rows: one flat out-of-place copy with the cache
+    policy of the selected kernel (`_nt` loads + stores, `_nts` stores, `_ntl` loads non-temporal).  100 x 640 x 480: the
+    row pass as a flat copy x -> out with non-temporal loads + 16-column x 640-row tiles in place on `out`.  10 x 128^3:
+    the plane pass as a flat copy with the plane kernel's 136 KB of LDS reserved (one workgroup per CU, one LDS round trip)
+    + 32-column x 128-row tiles in place."""
+    import ctypes
+    L = probe_lib()
+    if L is None or x.dtype != out.dtype or x.shape != out.shape or x.element_size() != 4:
+        return None
+    shape = WORKLOADS[name][0]
+    n = 1
+    for d in shape:
+        n *= d
+    ms = ctypes.c_float()
+
+    def flat(nt, lds=0, wg=8):
+        rc = L.probe_copy_flat(x.data_ptr(), out.data_ptr(), n, nt, lds, wg, iters, None, ctypes.byref(ms))
+        return round(ms.value, 5) if rc == 0 else None
+
+    def cols(outer, npts, inner, w, wg):
+        rc = L.probe_copy_cols(out.data_ptr(), out.data_ptr(), outer, npts, inner, w, wg, iters, None, ctypes.byref(ms))
+        return round(ms.value, 5) if rc == 0 else None
+
+    passes = []
+    if len(shape) == 2:
+        k = kernels[0]
+        nt = 3 if k.endswith("_nt") else 2 if k.endswith("_nts") else 1 if k.endswith("_ntl") else 0
+        passes.append({"pass": f"flat copy x -> out, nt={nt} ({k})", "ms": flat(nt)})
+    elif name == "2d_100x640x480":
+        passes.append({"pass": "rows480 as a flat copy x -> out, non-temporal loads", "ms": flat(1)})
+        passes.append({"pass": "cols640: 16-column x 640-row tiles in place on out, 80 KB of LDS, one LDS round trip",
+                       "ms": cols(shape[0], 640, 480, 16, 1)})
+    elif name == "3d_10x128x128x128":
+        passes.append({"pass": "plane128x128 as a flat copy x -> out, 136 KB of LDS reserved (1 workgroup per CU), one "
+                               "LDS round trip", "ms": flat(0, 136 * 1024 + 1024, 1)})
+        passes.append({"pass": "cols128: 32-column x 128-row tiles in place on out, 32 KB of LDS",
+                       "ms": cols(shape[0], 128, 128 * 128, 32, 4)})
+    else:
+        return None
+    if any(p["ms"] is None for p in passes):
+        return None
+    return passes
 
 
 def vendor_compare(timeout_s=240):
@@ -250,7 +322,7 @@ def live_pmc_traffic(workload, timeout_s=60):
             d = os.path.join(tmp, counter)
             cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__), "--workload", workload, "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
-                   "--no-configs", "--no-strong-leg", "--no-compare-vendor", "--no-live-pmc"]
+                   "--no-configs", "--no-strong-leg", "--no-compare-vendor", "--no-live-pmc", "--no-copy-ceiling"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             if r.returncode:
                 return None
@@ -297,6 +369,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not collect roofline.traffic with rocprofv3 child runs (N=1, headline workload only); the "
                          "committed profile is used instead")
+    ap.add_argument("--no-copy-ceiling", action="store_true",
+                    help="skip roofline.copy (copy kernels with the passes' tile shapes, tools/libmifft_probe.so)")
     ap.add_argument("--faithful", action="store_true", help="force the literal stage-per-pass kernel family")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="arithmetic type (BASELINE metric: f32)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -443,8 +517,20 @@ class Bench:
             elems *= d
         # one complex (or real) read + one complex write per element, per exec on ONE gpu
         algo_bytes = (2.0 + comps) * self.esz * elems
-        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
+        achieved = algo_bytes / (ms_per_step * 1e-3) / 1e9          # the K timed steps
+        achieved_ev = algo_bytes / (launch_ms * 1e-3) / 1e9         # the separate HIP-event loop
         kernels = [plan.kernel_name(d) for d in range(len(shape) - 1)]
+        copy = None
+        if comps == 2 and self.args.dtype == "f32" and not self.args.no_copy_ceiling:
+            passes = copy_ceiling(name, kernels, x, out)
+            if passes:
+                cms = sum(p["ms"] for p in passes)
+                copy = {"ms": round(cms, 5), "frac": round(algo_bytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "fft_over_copy": round(ms_per_step / cms, 4), "passes": passes,
+                        "what": "copy kernels with the passes' tile shapes and cache policy (tools/copy_probe.hip), HIP "
+                                "events over 30 launches each, same process, right after the timed steps"}
+                # the copies overwrote `out`: leave the tensors as a transform left them
+                mf.fft(out, x, self.ctx, plan=plan)
         traffic = measured_traffic(name, kernels)
         live = getattr(self, "live_traffic", {}).get(name)
         if live and len(live) == len(set(kernels)):
@@ -463,6 +549,9 @@ class Bench:
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_source": "algorithmic bytes / ms_per_step of the timed steps",
+                "frac_hip_events": round(achieved_ev / HBM_PEAK_GBS, 4),
+                "copy": copy,
                 "traffic": traffic[0] if traffic else None,
                 "traffic_source": (traffic[1] if traffic[1].startswith("live") else
                                    traffic[1] + " (committed rocprofv3 --pmc passes of this command)") if traffic else None,
