@@ -32,7 +32,9 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
         tp.n_tiles = (tp.n_rows + C::TILE - 1) / C::TILE;
     }
     auto k = tile_kernel<C>;
-    const long long grid = tile_grid<C>(plan.num_cus, tp.n_tiles);
+    // workgroups per CU of the persistent grid: the LDS / wave-count formula unless the table carries a measured value for
+    // this kernel (kGridPerCu, kernels_fast.hip)
+    const long long grid = tile_grid<C>(plan.num_cus, tp.n_tiles, pass.wg_per_cu);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::THREADS), C::LDS_BYTES, stream, tp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_error(e, "tile_kernel launch");

@@ -1,5 +1,8 @@
 // kernels_fast.hip -- configuration table + launchers of the register-butterfly Stockham tile
 // kernels (template: tile_kernel.h) for MI355X (gfx950).
+#include <cstdlib>
+#include <cstring>
+
 #include "fast_table.h"
 
 namespace mifft {
@@ -53,7 +56,17 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_SMALL_ST("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
     MIFFT_CFG_SMALL_ST_R("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
     MIFFT_CFG_CR("rows93_31x3", float, MIFFT_F32, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_LDS, 3, false),
+#if defined(MIFFT_ALT_ROWS480) && MIFFT_ALT_ROWS480 == 1   // A/B builds only (tools/ab_lib.sh)
+    MIFFT_CFG_NTL("rows480_6x8x10_t8x512", float, MIFFT_F32, 480, 3, 6, 8, 10, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+#elif defined(MIFFT_ALT_ROWS480) && MIFFT_ALT_ROWS480 == 2
+    MIFFT_CFG_NTL("rows480_5x4x4x6_t8x512", float, MIFFT_F32, 480, 4, 5, 4, 4, 6, 8, 512, false, true, true, TW_LDS, 2, false),
+#elif defined(MIFFT_ALT_ROWS480) && MIFFT_ALT_ROWS480 == 3
+    MIFFT_CFG_NTL("rows480_10x6x8_t8x384", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 384, false, true, true, TW_LDS, 2, false),
+#elif defined(MIFFT_ALT_ROWS480) && MIFFT_ALT_ROWS480 == 4
+    MIFFT_CFG_NTL("rows480_4x4x5x6_t4x256", float, MIFFT_F32, 480, 4, 4, 4, 5, 6, 4, 256, false, true, true, TW_LDS, 2, false),
+#else
     MIFFT_CFG_NTL("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+#endif
     MIFFT_CFG_NTL("rows640_10x8x8", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_NTL_R("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_MID_ST("rows480_10x6x8", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
@@ -152,7 +165,7 @@ static int launch_plane(const Plan& plan, const DimPass& pass, const void* in, v
     tp.n_tiles = count * pass.outer;  // planes
     tp.reverse = pass.reverse;
     auto k = plane_kernel<CR, CC>;
-    const long long grid = tile_grid<CR>(plan.num_cus, tp.n_tiles);
+    const long long grid = tile_grid<CR>(plan.num_cus, tp.n_tiles, pass.wg_per_cu);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(CR::THREADS), CR::LDS_BYTES, stream, tp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_error(e, "plane_kernel launch");
@@ -402,6 +415,25 @@ bool nts_window_bytes(double total_bytes) {
 }
 bool nts_window(const Plan& plan, double total_bytes) { return plan.ndim == 1 && nts_window_bytes(total_bytes); }
 
+// Measured workgroups-per-CU of the persistent grid where the LDS / wave-count formula of tile_grid<> is not the best choice
+// (tools/grid_sweep.py, one box, interleaved).  Name prefixes: a value applies to every twin of the configuration.
+struct GridPerCu {
+    const char* prefix;
+    int per_cu;
+};
+static const GridPerCu kGridPerCu[] = {
+    {"rows480_10x6x8", 3},   // 136-148 VGPRs: three workgroups resident, four launched left a quarter of the tiles to a thin tail
+};
+
+static int grid_per_cu_of(const char* name) {
+#ifdef MIFFT_EXPERIMENTAL  // lab knob: MIFFT_GRID_PER_CU=<n> forces every table kernel's grid (tools/grid_sweep.py)
+    if (const char* e = getenv("MIFFT_GRID_PER_CU")) return atoi(e);
+#endif
+    for (const GridPerCu& g : kGridPerCu)
+        if (strncmp(name, g.prefix, strlen(g.prefix)) == 0) return g.per_cu;
+    return 0;
+}
+
 bool select_fast(const Plan& plan, DimPass& pass) {
     // fast families read real or complex input of the output dtype; integer input and mixed
     // precision run on the generic family
@@ -431,6 +463,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         pass.threads = e.threads;
         pass.lds_bytes = e.lds;
         pass.ld = (int)pass.N;
+        pass.wg_per_cu = grid_per_cu_of(e.name);
         return true;
     };
     for (const FastEntry& e : kFastTable)  // hand-tuned entries win

@@ -71,6 +71,7 @@ struct DimPass {
     void* jit_fn = nullptr;           // runtime-compiled kernel (hipFunction_t) of kernels_jit.cpp passes
     void* d_aux3 = nullptr;           // TSTORE passes: [tile][N] table of W^(c*k1) for the columns of one tile
     bool reverse = false;             // in-place pass that walks its tiles last-to-first (TileParams::reverse)
+    int wg_per_cu = 0;                // workgroups per CU of the persistent grid (0 = the LDS / wave-count formula)
 };
 
 struct Plan {

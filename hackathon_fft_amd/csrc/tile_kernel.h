@@ -1274,10 +1274,57 @@ MIFFT_DEV void wp_row_passes(const TileParams& p, cpx<typename CR::T>* lds, cpx<
     }
 }
 
-template <class CR, class CC, int PAD, int I, class Hook, class Hook2>
+// WL ("wide last"): the LAST column pass is not wave-private.  Behind one more workgroup barrier its butterflies are dealt
+// over the whole workgroup with lanes along the contiguous axis, so that a wave's store instruction writes 64 adjacent
+// columns of one row (512-byte runs) instead of CPW columns of 64 / CPW rows (64-byte runs at CPW = 8: every 128-byte line
+// written half by one wave and half by its neighbour).  Three workgroup barriers per plane instead of two.
+template <class CR, class CC, int PAD, int I, class Hook, class Hook2, bool WL = false>
 MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long long base, int wave, int lane,
                              Hook before_stores, Hook2 between) {
-    if constexpr (I < CC::NP) {
+    if constexpr (WL && I == CC::NP - 1 && I > 0) {
+        using G = WavePlane<CR, CC, PAD>;
+        using T = typename CR::T;
+        using V = cpx<T>;
+        constexpr int R = CC::R(I), P = CC::P(I), NB = CC::NB(I);
+        static_assert((NB * G::N2) % G::THREADS == 0 && G::THREADS % G::N2 == 0, "whole sweeps of the last column pass");
+        constexpr int KPT = NB * G::N2 / G::THREADS, BSTEP = G::THREADS / G::N2;
+        const V* ltw = lds + G::DATA + G::CSHIFT;
+        const int tid = wave * 64 + lane;
+        const int c = tid % G::N2, b0 = tid / G::N2;
+        __syncthreads();  // every wave's scatter of pass NP-2 is complete
+        V v[KPT][R];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int b = b0 + k * BSTEP;
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[k][j] = lds[(b + j * NB) * G::PITCH + c];
+            const int pp = b % P;
+#pragma unroll
+            for (int j = 1; j < R; ++j) v[k][j] = cmul(v[k][j], ltw[CC::TWL_OFF(I) + (j - 1) * P + pp]);
+        }
+        MIFFT_STAMP(G, 4);
+        __syncthreads();  // last LDS read of this plane
+        MIFFT_STAMP(G, 5);
+        before_stores();
+        MIFFT_STAMP(G, 6);
+        V* gout = (V*)p.out;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int b = b0 + k * BSTEP;
+            Dft<R, T, 1>::run(v[k]);
+            const int q = b / P, pp = b - q * P, o0 = q * P * R + pp;
+            const unsigned off = (unsigned)o0 * (unsigned)G::N2 + (unsigned)c;
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                V y = v[k][s];
+                if (p.inverse) {
+                    y.x *= (T)p.scale;
+                    y.y *= -(T)p.scale;
+                }
+                gstore<(CC::NT & 2) != 0>(gout + base + (long long)s * P * G::N2 + off, y);
+            }
+        }
+    } else if constexpr (I < CC::NP) {
         using G = WavePlane<CR, CC, PAD>;
         using T = typename CR::T;
         using V = cpx<T>;
@@ -1330,7 +1377,7 @@ MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long
         }
         if constexpr (I < CC::NP - 1) wave_lds_fence();
         if constexpr (I == 0 && CC::NP > 1) between(IntC<3>{});
-        wp_col_passes<CR, CC, PAD, I + 1>(p, lds, base, wave, lane, before_stores, between);
+        wp_col_passes<CR, CC, PAD, I + 1, Hook, Hook2, WL>(p, lds, base, wave, lane, before_stores, between);
     }
 }
 
@@ -1340,7 +1387,7 @@ MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long
 // transforms over gamma, its last pass multiplies by W_M^(rho kc), the column side transforms over rho and stores the
 // result in natural order.  Twiddles of one 128-point side + a two-level table of N1 + N2 entries replace the M-entry
 // table a one-row-per-workgroup tile kernel reads from L2 in every pass (p.thi = the M-entry table W_M^m, forward).
-template <class CR, class CC, int PAD, bool FS = false>
+template <class CR, class CC, int PAD, bool FS = false, bool WL = false>
 __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const TileParams p) {
     using G = WavePlane<CR, CC, PAD>;
     using T = typename CR::T;
@@ -1405,7 +1452,7 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const T
         __syncthreads();  // hand-over: every row is complete before any column starts
         MIFFT_STAMP(G, 2);  // hand-over barrier
         slice(IntC<2>{});
-        wp_col_passes<CR, CC, PAD, 0>(p, lds, base, wave, lane, drain, slice);
+        wp_col_passes<CR, CC, PAD, 0, decltype(drain), decltype(slice), WL>(p, lds, base, wave, lane, drain, slice);
         MIFFT_STAMP(G, 3);  // column passes incl. the barrier behind the last gather and the HBM stores
         if (!CR::PREFETCH && tn < p.n_tiles) wp_load_rows<CR, CC, PAD, 0, 1, FS>(p, pre, tile_id(p, tn) * PLANE, wave, lane);
     }
@@ -1533,7 +1580,11 @@ __global__ __launch_bounds__(CR::THREADS, 1) void image_kernel(const ImageParams
     }
 }
 
-// persistent grid: enough workgroups to fill every CU to its LDS / wave limit
+// persistent grid: enough workgroups to fill every CU to its LDS / wave limit.  The formula ignores registers, so a kernel
+// that holds fewer workgroups than it launches leaves the surplus waiting for a slot; whether that hurts is kernel by kernel
+// (rows480: 4 launched / 3 resident 0.0873 ms, 3 launched 0.0834 ms; rows128: 8 launched / 5 resident is 2-7 % FASTER than
+// 5 launched -- the late workgroups fill the holes of the ragged end), so measured per-kernel values override the formula
+// (`wg_per_cu_override`, from kGridPerCu in kernels_fast.hip) instead of a general occupancy rule.
 template <class C>
 inline long long tile_grid(int num_cus, long long n_tiles, int wg_per_cu_override = 0) {
     long long per_cu = (160 * 1024) / (long long)(C::LDS_BYTES ? C::LDS_BYTES : 1);

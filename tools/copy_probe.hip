@@ -215,4 +215,25 @@ int probe_copy_cols(const void* in, void* out, long long outer, int n, int inner
     return time_launches((hipStream_t)stream, iters, ms_out, launch_cols, &a);
 }
 
+// The two passes of an N-D transform as copies, ALTERNATING like the transform does (pass 1 out of place x -> out as a flat
+// copy, pass 2 in place on out as column tiles): what the second pass finds in the caches depends on the first, so the pair
+// is timed as a pair.  ms_out[0] = average per pair; per-pass figures come from the separate entry points above.
+int probe_copy_pair(const void* x, void* out, long long n_elems, int nt1, int lds1, int wg1, long long outer, int n, int inner,
+                    int w, int wg2, int iters, void* stream, float* ms_out) {
+    if (!x || !out || !ms_out || n_elems < 1 || iters < 1 || inner % w != 0 || lds1 > 160 * 1024) return -1;
+    FlatArgs a{(const f2*)x, (f2*)out, n_elems, nt1, lds1, wg1 > 0 ? wg1 : 8, num_cus()};
+    ColsArgs c{(const f2*)out, (f2*)out, outer, n, inner, w, wg2 > 0 ? wg2 : 1, num_cus()};
+    struct Pair {
+        FlatArgs* a;
+        ColsArgs* c;
+    } pr{&a, &c};
+    return time_launches((hipStream_t)stream, iters, ms_out,
+                         [](void* p, hipStream_t s) {
+                             Pair* q = (Pair*)p;
+                             launch_flat(q->a, s);
+                             launch_cols(q->c, s);
+                         },
+                         &pr);
+}
+
 }  // extern "C"

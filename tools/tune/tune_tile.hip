@@ -76,6 +76,14 @@ Variant make(const char* name) {
             set = true;
         }
         long long grid = tile_grid<C>(g_cus, tp.n_tiles, g_wg_override);
+        static bool told = false;
+        if (!told && getenv("TUNE_OCC")) {  // resident workgroups per CU as the runtime sees them
+            int nb = 0;
+            CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k, C::THREADS, C::LDS_BYTES + STAMP_LDS));
+            printf("occupancy: %d workgroups of %d threads, %zu B LDS per CU; grid %lld for %lld tiles\n", nb, C::THREADS,
+                   (size_t)C::LDS_BYTES, grid, tp.n_tiles);
+            told = true;
+        }
 #ifdef MIFFT_STAMPS
         tp.tcol = g_stamps;
         g_last_grid = grid;
@@ -197,7 +205,7 @@ Variant make_plane(const char* name) {
     return v;
 }
 
-template <class CR, class CC, int PAD>
+template <class CR, class CC, int PAD, bool WL = false>
 Variant make_plane_wp(const char* name) {
     Variant v;
     v.name = name;
@@ -213,7 +221,7 @@ Variant make_plane_wp(const char* name) {
         tp.inner = CC::TILE;
         tp.tiles_per_outer = 1;
         tp.n_tiles = batch * outer;  // planes
-        auto k = plane_kernel_wp<CR, CC, PAD>;
+        auto k = plane_kernel_wp<CR, CC, PAD, false, WL>;
         static bool set = false;
         if (!set && G::LDS_BYTES > 64 * 1024) {
             CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
@@ -261,6 +269,11 @@ Variant make_plane_wp(const char* name) {
 #define PLW(NAME, PN, PAD, THR, MINW, PF, R0, R1, R2, R3, NP)                                                    \
     make_plane_wp<TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, false, true, false, TW_LDS, MINW, PF>,         \
                   TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, true, false, true, TW_LDS, MINW, false>, PAD>(NAME)
+
+// wave-private plane with the LAST column pass dealt over the whole workgroup (512-byte store runs, one more barrier)
+#define PLWL(NAME, PN, PAD, THR, MINW, PF, R0, R1, R2, R3, NP)                                                   \
+    make_plane_wp<TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, false, true, false, TW_LDS, MINW, PF>,         \
+                  TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, true, false, true, TW_LDS, MINW, false>, PAD, true>(NAME)
 
 #define PLN(NAME, PN, THR, MINW, PF, R0, R1, R2, R3, NP)                                                         \
     make_plane<TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, false, true, false, TW_LDS, MINW, PF>,            \
@@ -497,6 +510,11 @@ int main(int argc, char** argv) {
         PLW("wp 16x8 512 w2 pf pad8", 128, 8, 512, 2, true, 16, 8, 1, 1, 2),
         PLW("wp 16x8 512 w2 pf pad16", 128, 16, 512, 2, true, 16, 8, 1, 1, 2),
         PLW("wp 8x16 512 w2 pf pad8", 128, 8, 512, 2, true, 8, 16, 1, 1, 2),
+        PLWL("wpwl 8x16 1024 w4 pf pad8", 128, 8, 1024, 4, true, 8, 16, 1, 1, 2),
+        PLWL("wpwl 16x8 1024 w4 pf pad8", 128, 8, 1024, 4, true, 16, 8, 1, 1, 2),
+        PLWL("wpwl 8x16 1024 w4 pf pad0", 128, 0, 1024, 4, true, 8, 16, 1, 1, 2),
+        PLWL("wpwl 8x16 512 w2 pf pad8", 128, 8, 512, 2, true, 8, 16, 1, 1, 2),
+        PLWL("wpwl 8x4x4 1024 w4 pf pad8", 128, 8, 1024, 4, true, 8, 4, 4, 1, 3),
     };
 #elif GROUP == 13  // ---- 100 x 64^3: fused y+x planes, 6400 planes of 64x64 ----
     const long long batch = 100, outer = 64, inner = 1;
@@ -639,6 +657,13 @@ int main(int argc, char** argv) {
         VW("c640 8x4x4x5 t16 512 wsub pf", float, 640, 4, 8, 4, 4, 5, 16, 512, true, true, true, TW_LDS, 1, true),
         VW("c640 8x5x4x4 t16 512 wsub pf", float, 640, 4, 8, 5, 4, 4, 16, 512, true, true, true, TW_LDS, 1, true),
         VW("c640 10x4x4x4 t16 640 wsub pf", float, 640, 4, 10, 4, 4, 4, 16, 640, true, true, true, TW_LDS, 1, true),
+        // 80 KB of LDS per workgroup (twiddles from the global table): TWO workgroups per CU
+        VW("c640 10x8x8 t16 640 wsub glb w5", float, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_GLOBAL, 5, false),
+        VW("c640 10x8x8 t16 640 wsub glb w3", float, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_GLOBAL, 3, false),
+        VW("c640 10x8x8 t16 640 wsub glb w5 pf", float, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_GLOBAL, 5, true),
+        VW("c640 10x8x8 t16 320 wsub glb w3", float, 640, 3, 10, 8, 8, 1, 16, 320, true, true, true, TW_GLOBAL, 3, false),
+        VW("c640 10x8x8 t16 320 wsub glb w3 pf", float, 640, 3, 10, 8, 8, 1, 16, 320, true, true, true, TW_GLOBAL, 3, true),
+        V("c640 10x8x8 t16 512 glb w4", float, 640, 3, 10, 8, 8, 1, 16, 512, true, true, true, TW_GLOBAL, 4, false),
     };
 #elif GROUP == 21  // ---- four-step passes / long strided dims: columns of 1024 with WSUB ----
     const long long batch = 64, outer = 1, inner = 1024;
