@@ -264,6 +264,7 @@ def _as_interleaved(x: "torch.Tensor"):
 
 _PLAN_CACHE: "collections.OrderedDict" = collections.OrderedDict()
 _PLAN_CACHE_SIZE = 32
+_PLAN_CACHE_SCRATCH_BYTES = 8 << 30  # ... and at most this much plan-owned scratch (long-strided / three-launch routes)
 _PLAN_CACHE_LOCK = threading.RLock()
 
 
@@ -297,7 +298,8 @@ def _cached_plan_locked(in_dtype, out_dtype, in_shape, out_shape, radices, inver
             plan = plan_fft(in_dtype, out_dtype, in_shape, out_shape, bases=[_prime_factors(int(n)) for n in in_shape[1:-1]],
                             inverse=inverse, faithful_stages=faithful_stages, ctx=DeviceContext(device))
         _PLAN_CACHE[key] = plan
-        while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+        while len(_PLAN_CACHE) > 1 and (len(_PLAN_CACHE) > _PLAN_CACHE_SIZE or
+                                        sum(q.scratch_bytes for q in _PLAN_CACHE.values()) > _PLAN_CACHE_SCRATCH_BYTES):
             _, old = _PLAN_CACHE.popitem(last=False)
             torch.cuda.synchronize(old.device)  # nothing enqueued with the evicted plan may still run
             old.close()
@@ -333,10 +335,13 @@ def _run(x: "torch.Tensor", *, radices, inverse: bool, out_dtype, faithful_stage
     if out_dtype is None:
         out_dtype = xr.dtype if xr.dtype in (torch.float32, torch.float64) else torch.float64
     out_shape = tuple(xr.shape[:-1]) + (2,)
-    plan = _cached_plan(xr.dtype, out_dtype, tuple(xr.shape), out_shape, radices, inverse, faithful_stages,
-                        xr.device.index)
     out = torch.empty(out_shape, dtype=out_dtype, device=xr.device)
-    fft(out, xr, DeviceContext(xr.device.index), plan=plan)  # asynchronous on the current stream, like torch ops
+    # lookup AND enqueue under the cache lock: another thread that inserts a plan may evict (synchronise + close) only
+    # plans that have nothing left to enqueue
+    with _PLAN_CACHE_LOCK:
+        plan = _cached_plan_locked(xr.dtype, out_dtype, tuple(xr.shape), out_shape, radices, inverse, faithful_stages,
+                                   xr.device.index)
+        fft(out, xr, DeviceContext(xr.device.index), plan=plan)  # asynchronous on the current stream, like torch ops
     return torch.view_as_complex(out) if was_complex else out
 
 

@@ -211,6 +211,54 @@ struct DftOddPrime {
             outputs<s + 1>(v, x0, a, b);
         }
     }
+    // EMIT-AS-YOU-GO form: the sums a_j / differences b_j overwrite the inputs in place (v[j] <- a_j, v[R-j] <- b_j) and
+    // every conjugate output pair is handed to `emit(s, X_s)` the moment it exists, so the R outputs never live in
+    // registers beside the R - 1 sums (radix 31: ~70 live VGPRs instead of ~130).  Same operations in the same order as
+    // run(): results are bit-identical.
+    template <int s, class Emit>
+    static MIFFT_DEV void emit_pairs(const cpx<T>* v, cpx<T> x0, Emit& emit) {
+        if constexpr (s <= H) {
+            cpx<T> A = x0, B = {(T)0, (T)0};
+            acc_inplace<s, 1>(v, A, B);
+            emit(s, cpx<T>{A.x + B.y, A.y - B.x});
+            emit(R - s, cpx<T>{A.x - B.y, A.y + B.x});
+            emit_pairs<s + 1>(v, x0, emit);
+        }
+    }
+    template <int s, int j>
+    static MIFFT_DEV void acc_inplace(const cpx<T>* v, cpx<T>& A, cpx<T>& B) {  // a_j at v[j * S], b_j at v[(R - j) * S]
+        if constexpr (j <= H) {
+            constexpr cx_pair cs = cx_cossin((long long)j * s, R);
+            constexpr T c = (T)cs.c, sn = (T)cs.s;
+#ifndef MIFFT_NO_PRIME_FMA
+            A.x = fma_t(c, v[j * S].x, A.x);
+            A.y = fma_t(c, v[j * S].y, A.y);
+            B.x = fma_t(sn, v[(R - j) * S].x, B.x);
+            B.y = fma_t(sn, v[(R - j) * S].y, B.y);
+#else
+            A.x += c * v[j * S].x;
+            A.y += c * v[j * S].y;
+            B.x += sn * v[(R - j) * S].x;
+            B.y += sn * v[(R - j) * S].y;
+#endif
+            acc_inplace<s, j + 1>(v, A, B);
+        }
+    }
+    template <class Emit>
+    static MIFFT_DEV void run_emit(cpx<T>* v, Emit& emit) {
+        const cpx<T> x0 = v[0];
+        cpx<T> sum = x0;
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            const cpx<T> u = v[j * S], w = v[(R - j) * S];
+            v[j * S] = u + w;
+            v[(R - j) * S] = u - w;
+        }
+#pragma unroll
+        for (int j = 1; j <= H; ++j) sum = sum + v[j * S];
+        emit(0, sum);
+        emit_pairs<1>(v, x0, emit);
+    }
     static MIFFT_DEV void run(cpx<T>* v) {
 #ifdef MIFFT_ABLATE_PRIME_DFT  // timing experiment only: how fast is the kernel around a free butterfly?
         if (R > 16) return;

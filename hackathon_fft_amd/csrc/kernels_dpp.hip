@@ -31,6 +31,7 @@
 // RPW = 16 (12 of 16 lanes busy) makes a wave's block 16 * 744 B = 93 whole 128-byte lines, so that its linear store
 // never shares a line with another wave; RPW = 20 (15 of 16 lanes busy) does not.
 #include "fast_table.h"
+#include "mifft_config.h"
 
 namespace mifft {
 
@@ -153,22 +154,18 @@ static int launch_dpp3(const Plan& plan, const DimPass& pass, const void* in, vo
 
 // contiguous dimension of N = 3 * R0 points, complex fp32 in and out
 bool select_dpp_rows(const Plan& plan, DimPass& pass) {
-    const char* on = getenv("MIFFT_DPP");
-    if (!(on && on[0] == '1')) return false;  // opt-in: slower than the tile kernel (see the header)
+    if (!config().dpp) return false;  // opt-in (MIFFT_DPP=1, lab build): slower than the tile kernel (see the header)
     if (pass.inner != 1 || !pass.first || plan.out_dtype != MIFFT_F32 || plan.in_dtype != MIFFT_F32 ||
         plan.in_components != 2)
         return false;
-    const bool streaming = plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0 > 0.6e9;
-    int variant = 0;  // tuning knob: 0 = 16 rows per wave, 1 = 20 rows per wave; +2 = plain stores at streaming sizes
-    if (const char* e = getenv("MIFFT_DPP_VARIANT")) variant = atoi(e);
-    const bool nt = streaming && !(variant & 2);
-    const int rpw = (variant & 1) ? 20 : 16;
+    const bool streaming = plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0 > config().streaming_min_bytes;
+    // (16 rows per wave; the 20-row layout -- 15 of 16 lanes busy, blocks that are no whole number of lines -- measured
+    //  0.20 ms against 0.163 and went with the MIFFT_DPP_VARIANT knob in round 3)
+    const bool nt = streaming;
+    const int rpw = 16;
     if (pass.N == 93) {
         pass.kernel_name = nt ? "rows93_31x3_dpp_nts" : "rows93_31x3_dpp";
-        if (rpw == 16)
-            pass.launch = nt ? launch_dpp3<31, true, 16> : launch_dpp3<31, false, 16>;
-        else
-            pass.launch = nt ? launch_dpp3<31, true, 20> : launch_dpp3<31, false, 20>;
+        pass.launch = nt ? launch_dpp3<31, true, 16> : launch_dpp3<31, false, 16>;
     } else {
         return false;
     }

@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "fast_table.h"
+#include "mifft_config.h"
 
 namespace mifft {
 
@@ -320,7 +321,9 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
         if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
         if (e.in_real != (pass.first && plan.in_components == 1)) continue;
         if (e.ntl && !(plan.cache_resident_nd && plan.ndim > 2)) continue;  // a 2-D plane is the only pass: nothing to keep
-        if (e.ntl && e.N1 == 128 && plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() < 210e6) continue;
+        if (e.ntl && e.N1 == 128 &&
+            plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() < config().nd_plane128_min_bytes)
+            continue;
         if (e.nts && !(plan.ndim == 2 && nts_window_bytes(plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0)))
             continue;
         pass.kernel_name = e.name;
@@ -371,8 +374,7 @@ static const Row2DEntry kRow2DTable[] = {
 };
 
 bool select_row2d(const Plan& plan, DimPass& pass) {
-    if (const char* e = getenv("MIFFT_ROW2D"))
-        if (e[0] == '0') return false;
+    if (!config().row2d) return false;  // (lab switch; always on in the product library)
     if (pass.inner != 1 || !pass.first || plan.in_dtype != plan.out_dtype) return false;
     for (const Row2DEntry& e : kRow2DTable) {
         if (e.M != pass.N || e.dtype != plan.out_dtype || e.in_real != (plan.in_components == 1)) continue;
@@ -408,10 +410,7 @@ bool select_fast_tstore(const Plan& plan, DimPass& pass) {
 }
 
 bool nts_window_bytes(double total_bytes) {
-    double lo = 0.25e9, hi = 0.55e9;
-    if (const char* e = getenv("MIFFT_NTS_MIN_BYTES")) lo = atof(e);
-    if (const char* e = getenv("MIFFT_NTS_MAX_BYTES")) hi = atof(e);
-    return total_bytes > lo && total_bytes <= hi;
+    return total_bytes > config().nts_min_bytes && total_bytes <= config().nts_max_bytes;
 }
 bool nts_window(const Plan& plan, double total_bytes) { return plan.ndim == 1 && nts_window_bytes(total_bytes); }
 
@@ -426,9 +425,7 @@ static const GridPerCu kGridPerCu[] = {
 };
 
 static int grid_per_cu_of(const char* name) {
-#ifdef MIFFT_EXPERIMENTAL  // lab knob: MIFFT_GRID_PER_CU=<n> forces every table kernel's grid (tools/grid_sweep.py)
-    if (const char* e = getenv("MIFFT_GRID_PER_CU")) return atoi(e);
-#endif
+    if (config().grid_per_cu > 0) return config().grid_per_cu;  // lab knob (tools/grid_sweep.py); 0 in the product library
     for (const GridPerCu& g : kGridPerCu)
         if (strncmp(name, g.prefix, strlen(g.prefix)) == 0) return g.per_cu;
     return 0;
@@ -441,7 +438,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
     const bool cols = pass.inner != 1;
     // read + write volume of one exec far beyond the 256-MB Infinity Cache -> non-temporal twins apply
     const double total_bytes = plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() * 2.0;
-    const bool streaming = total_bytes > 0.6e9;
+    const bool streaming = total_bytes > config().streaming_min_bytes;
     bool hand_table = true;  // the hand-tuned lengths keep their `_nts` twins up to the streaming threshold (0.6 GB), where
                              // the `_nt` twins take over: 50k x 1024 still gains 4-6 % with non-temporal stores
     auto try_entry = [&](const FastEntry& e) {
@@ -450,9 +447,9 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         if (e.stream_pref == 1 && !streaming) return false;
         if (e.stream_pref == 2 && !(plan.cache_resident_nd && pass.first)) return false;
         if (e.stream_pref == 3 && !(nts_window(plan, total_bytes) ||
-                                    (hand_table && plan.ndim == 1 && total_bytes > 0.25e9 && !streaming)))
+                                    (hand_table && plan.ndim == 1 && total_bytes > config().nts_min_bytes && !streaming)))
             return false;
-        if (e.stream_pref == 4 && !(plan.ndim == 1 && total_bytes > 0.05e9)) return false;
+        if (e.stream_pref == 4 && !(plan.ndim == 1 && total_bytes > config().nts_small_min_bytes)) return false;
         if (cols && e.tile > 16 && pass.inner % e.tile != 0) return false;  // wide tiles: whole tiles only
         // (a strided dimension with fewer columns than one tile still runs here: the ragged tile clamps its loads and
         //  masks its stores; the literal-stage alternative is an order of magnitude slower)

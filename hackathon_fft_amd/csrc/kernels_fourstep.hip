@@ -13,23 +13,24 @@
 #include <cstdlib>
 
 #include "fast_table.h"
+#include "mifft_config.h"
 
 namespace mifft {
 
 static constexpr int kL = 1024;
 
-// The plan scratch (one tensor of the output size).  MIFFT_TEST_FAIL_SCRATCH_ALLOC=1 makes this allocation fail the
-// way an exhausted device does, so that the roll-back of a half-built route can be tested on any GPU.
+// The plan scratch (one tensor of the output size).  In the lab build (-DMIFFT_TESTING) MIFFT_TEST_FAIL_SCRATCH_ALLOC=1 makes
+// this allocation fail the way an exhausted device does, so that the roll-back of a half-built route can be tested on any GPU.
 static hipError_t alloc_scratch(Plan& plan) {
     if (plan.d_scratch) return hipSuccess;
     plan.scratch_bytes = (size_t)plan.batch * (size_t)plan.prod * plan.out_elem_bytes();
     if (!plan.scratch_bytes) return hipSuccess;
-    if (const char* e = getenv("MIFFT_TEST_FAIL_SCRATCH_ALLOC")) {
-        if (e[0] == '1') {
-            plan.scratch_bytes = 0;
-            return hipErrorOutOfMemory;
-        }
+#ifdef MIFFT_TESTING  // fault injection exists in the lab build only
+    if (config().test_fail_scratch_alloc) {
+        plan.scratch_bytes = 0;
+        return hipErrorOutOfMemory;
     }
+#endif
     hipError_t e = hipMalloc(&plan.d_scratch, plan.scratch_bytes);
     if (e != hipSuccess) {
         plan.d_scratch = nullptr;
@@ -327,15 +328,14 @@ bool build_fourstep_strided(Plan& plan, int dim_index, std::string& why_not) {
         why_not = "contiguous dimension";
         return false;
     }
-    if (const char* e = getenv("MIFFT_FOURSTEP_STRIDED"))
-        if (e[0] == '0') {
-            why_not = "MIFFT_FOURSTEP_STRIDED=0";
-            return false;
-        }
-    // most balanced factorisation whose factors both have a fused column configuration (MIFFT_FS_N1 forces the first
-    // factor: tuning knob)
-    int64_t best1 = 0, best2 = 0, forced1 = 0;
-    if (const char* e = getenv("MIFFT_FS_N1")) forced1 = atoll(e);
+    if (!config().fourstep_strided) {  // (lab switch: forces the transposed route)
+        why_not = "MIFFT_FOURSTEP_STRIDED=0";
+        return false;
+    }
+    // most balanced factorisation whose factors both have a fused column configuration (Config::fs_n1 forces the first
+    // factor: lab knob)
+    int64_t best1 = 0, best2 = 0;
+    const int64_t forced1 = config().fs_n1;
     double best_score = 1e300;
     for (int64_t n1 = 2; n1 <= 4096 && n1 < N; ++n1) {
         if (N % n1 || (forced1 > 0 && n1 != forced1)) continue;

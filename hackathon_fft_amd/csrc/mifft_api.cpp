@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "mifft_config.h"
 #include "mifft_internal.h"
 
 namespace mifft {
@@ -267,23 +268,20 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) p.num_cus = prop.multiProcessorCount;
 
-    // ---- Infinity-Cache policy for N-D transforms.  MIFFT_ND_CACHE overrides it: bit 0 = the first pass reads x with
-    //      non-temporal loads when `out` fits the 256-MiB cache, so that x does not displace the row results the next pass
-    //      reads (100 x 640 x 480: rows 96.2 -> 92.6 us, columns 102.9 -> 88.1 us); bit 1 = in-place passes walk their
+    // ---- Infinity-Cache policy for N-D transforms (thresholds: mifft_config.h).  Bit 0 of nd_mode = the first pass reads x
+    //      with non-temporal loads when `out` fits the 256-MiB cache, so that x does not displace the row results the next
+    //      pass reads (100 x 640 x 480: rows 96.2 -> 92.6 us, columns 102.9 -> 88.1 us); bit 1 = in-place passes walk their
     //      tiles in alternating directions, starting with the lines written last (10 x 128^3: 0.131 -> 0.128 ms,
     //      100 x 64^3 with both: 0.151 -> 0.139 ms).  Results are bit-identical in every mode. ----
-    int nd_mode = 3;
-    if (const char* ev = getenv("MIFFT_ND_CACHE")) nd_mode = atoi(ev);
+    config_refresh();  // (lab builds re-read their MIFFT_* switches per plan; a no-op in the product library)
+    const Config& cfg = config();
+    const int nd_mode = cfg.nd_mode;
     {
-        double max_mb = 250.0;
-        if (const char* ev = getenv("MIFFT_ND_CACHE_MAX_MB")) max_mb = atof(ev);
         const double out_bytes = p.size_batch() * (double)p.prod * (double)p.out_elem_bytes();
         // ... and only when x and out together do NOT fit: below ~160 MB per tensor everything stays cache-resident
         // between the passes (and between execs), and non-temporal loads of x cost 6-9 % (100-image batches of
         // 640 x 480 at 59 / 118 MB: 0.0510 -> 0.0551 / 0.0834 -> 0.0905 ms, 64^3 the same; tools/nd_size_probe.py)
-        double min_mb = 160.0;
-        if (const char* ev = getenv("MIFFT_ND_CACHE_MIN_MB")) min_mb = atof(ev);
-        p.cache_resident_nd = ndim >= 2 && (nd_mode & 1) && out_bytes <= max_mb * 1e6 && out_bytes >= min_mb * 1e6;
+        p.cache_resident_nd = ndim >= 2 && (nd_mode & 1) && out_bytes <= cfg.nd_out_max_bytes && out_bytes >= cfg.nd_out_min_bytes;
     }
 
     // ---- passes in execution order: last dimension first ----
@@ -320,7 +318,11 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
                 pl.outer = 1;
                 for (int k = 0; k < i - 1; ++k) pl.outer *= dims[k];
                 std::string whyp;
-                if (select_fast_plane(p, pl) || select_jit_plane(p, pl, whyp) || select_jit_image(p, pl, whyp)) {
+                bool fused = select_fast_plane(p, pl) || select_jit_plane(p, pl, whyp);
+#ifdef MIFFT_EXPERIMENTAL  // L2-resident image kernel: a documented negative result, lab builds only
+                if (!fused) fused = select_jit_image(p, pl, whyp);
+#endif
+                if (fused) {
                     ps = pl;
                     ok = true;
                     --i;  // dimension i-1 is covered by this pass
@@ -330,13 +332,11 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
             // Long rows of a big batched 1-D transform: two column-tile passes (four-step) move the tensor twice
             // at ~4.7 TB/s each (256 MB: 0.22 ms), which beats one workgroup per 128-KiB row (one workgroup per CU,
             // 2 TB/s: 0.26 ms) once the tensor fills the GPU in both passes; 8192-point rows are still faster in
-            // one kernel (0.13 ms).  MIFFT_FOURSTEP_MIN_N overrides the threshold
-            // (0 = never prefer the four-step).
+            // one kernel (0.13 ms).  (Config::fourstep_min_n; 0 = never prefer the four-step.)
             if (!ok && ndim == 1 && p.in_components == 2 && p.in_dtype == p.out_dtype) {
-                long long min_n = 16384;
-                if (const char* e = getenv("MIFFT_FOURSTEP_MIN_N")) min_n = atoll(e);
+                const long long min_n = cfg.fourstep_min_n;
                 const double bytes = p.size_batch() * (double)ps.N * (double)p.out_elem_bytes();
-                if (min_n > 0 && ps.N >= min_n && bytes >= 32e6) {
+                if (min_n > 0 && ps.N >= min_n && bytes >= cfg.fourstep_min_bytes) {
                     std::string why4;
                     const size_t before = p.passes.size();
                     if (build_fourstep(p, i, why4) && p.passes.size() == before + 2) continue;
@@ -361,25 +361,24 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
                     }
                 }
             }
-            // tuning knob: strided dimensions of at least MIFFT_FS_STRIDED_MIN_N points try the two-pass four-step before
-            // the single column tile (whose tile narrows to 8 / 4 columns = 64- / 32-byte runs beyond ~1300 / 2600 points)
-            if (!ok && ps.inner != 1) {
-                if (const char* e = getenv("MIFFT_FS_STRIDED_MIN_N")) {
-                    const long long min_n = atoll(e);
-                    std::string whyt;
-                    if (min_n > 0 && (long long)ps.N >= min_n && build_fourstep_strided(p, i, whyt)) continue;
-                    if (p.alloc_failed) {
-                        free_plan_device(p);
-                        delete h;
-                        return set_error(MIFFT_ERR_HIP, "four-step of strided dimension " + std::to_string(i) + ": " + whyt);
-                    }
+#ifdef MIFFT_EXPERIMENTAL
+            // lab knob: strided dimensions of at least Config::fs_strided_min_n points try the two-pass four-step before the
+            // single column tile (whose tile narrows to 8 / 4 columns = 64- / 32-byte runs beyond ~1300 / 2600 points)
+            if (!ok && ps.inner != 1 && cfg.fs_strided_min_n > 0 && (long long)ps.N >= cfg.fs_strided_min_n) {
+                std::string whyt;
+                if (build_fourstep_strided(p, i, whyt)) continue;
+                if (p.alloc_failed) {
+                    free_plan_device(p);
+                    delete h;
+                    return set_error(MIFFT_ERR_HIP, "four-step of strided dimension " + std::to_string(i) + ": " + whyt);
                 }
             }
             if (!ok) {
                 std::string whys;
-                ok = select_jit_streaming_rows(p, ps, whys);  // experiment switch, see kernels_jit.cpp
+                ok = select_jit_streaming_rows(p, ps, whys);  // streaming hints on runtime-specialised rows (negative result)
             }
-            if (!ok) ok = select_dpp_rows(p, ps);
+            if (!ok) ok = select_dpp_rows(p, ps);  // wave-shuffle radix 3 for N = 93 (negative result)
+#endif
             if (!ok) ok = select_fast(p, ps);
             // no table entry: specialise the tile kernel for this length now (strided dimensions up to 4096 points;
             // longer ones are better off on the transposed route below)

@@ -33,6 +33,11 @@
 
 #include "fft_radix.h"
 
+// odd prime radices from this size on use the emit-as-you-go butterfly in LDS-bound passes (pass_compute_scatter)
+#ifndef MIFFT_EMIT_PRIME_MIN
+#define MIFFT_EMIT_PRIME_MIN 17
+#endif
+
 namespace mifft {
 
 template <typename T> struct native_vec2;
@@ -545,11 +550,19 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
     for (int k = 0; k < IPT; ++k) {
         int c, b;
         if (item_of<C, I>(tid, k, c, b)) {
+            const int q = b / P, pp = b - q * P;
+            const int o0 = q * P * R + pp;
+            // large odd primes scatter every conjugate pair to LDS the moment it is computed (DftOddPrime::run_emit): the
+            // R outputs never exist in registers beside the R - 1 sums
+            if constexpr (!DST_GLOBAL && is_prime_ce(R) && R >= MIFFT_EMIT_PRIME_MIN) {
+                auto emit = [&](int s, V y) { lds[lds_index<C, I>(c, o0 + s * P)] = y; };
+                DftOddPrime<R, T, 1>::run_emit(v[k], emit);
+                MIFFT_FENCE();
+                continue;
+            }
 #ifndef MIFFT_ABLATE_MATH  // timing experiment only: data movement without butterflies / twiddles
             Dft<R, T, 1>::run(v[k]);
 #endif
-            const int q = b / P, pp = b - q * P;
-            const int o0 = q * P * R + pp;
             if constexpr (DST_GLOBAL && C::FS1) {
                 if (c < nv) {
                     // row k1 = o0 + s * P of this tile becomes row n2 * N1 + k1 of the other buffer, times W^(k1 * n2)
@@ -740,7 +753,10 @@ MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<
             } else {
                 load_pass0<C>(p, v, base, nv, tid);
             }
-            if (p.inverse) {
+            // inverse = conj(F(conj x)) / N.  A real input is its own conjugate: its imaginary parts stay the CONSTANT +0,
+            // which lets the compiler fold the imaginary half of the first butterflies away (radix 31 on real input: 176 ->
+            // VGPRs, no spill; a runtime -0 / +0 kept every one of them live).
+            if (p.inverse && !C::IN_REAL) {
 #pragma unroll
                 for (int k = 0; k < IPT; ++k)
 #pragma unroll
@@ -892,7 +908,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                     x = {gload_real<false>((const T*)p.in + gaddr<C>(p, base, cc, n)), (T)0};
                 else
                     x = gload<false>((const V*)p.in + gaddr<C>(p, base, cc, n));
-                if (p.inverse) x.y = -x.y;
+                if (p.inverse && !C::IN_REAL) x.y = -x.y;
                 lds[lds_index<C, -1>(c, n)] = x;
             }
             __syncthreads();
@@ -910,7 +926,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                         x.x = gload_real<(C::NT & 1) != 0>((const T*)p.in + base + f);
                     else
                         x = gload<(C::NT & 1) != 0>(gin + base + f);
-                    if (p.inverse) x.y = -x.y;
+                    if (p.inverse && !C::IN_REAL) x.y = -x.y;
                     lds[lds_index<C, -1>(c, n)] = x;
                 }
             }
@@ -1228,7 +1244,7 @@ MIFFT_DEV void wp_row_passes(const TileParams& p, cpx<typename CR::T>* lds, cpx<
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     v[k][j] = pre[k][j];
-                    if (p.inverse) v[k][j].y = -v[k][j].y;
+                    if (p.inverse && !CR::IN_REAL) v[k][j].y = -v[k][j].y;
                 }
             } else {
 #pragma unroll
@@ -1459,6 +1475,7 @@ __global__ __launch_bounds__(CR::THREADS, CR::MINW) void plane_kernel_wp(const T
     MIFFT_STAMP_DUMP(G, p);
 }
 
+#ifdef MIFFT_EXPERIMENTAL  // lab builds only: a documented negative result (DESIGN_EXPERIMENTS.md), not in libmifft.so
 // ---------------------------------------------------------------------------------------------
 // image_kernel<CR, CC>: the two innermost dimensions (N1 x N2, N2 contiguous) of images that do NOT fit LDS but fit
 // one XCD's 4-MB L2 (100 x 640 x 480: 2.4 MB each).  Every XCD owns whole images: its workgroups transform the rows
@@ -1579,6 +1596,8 @@ __global__ __launch_bounds__(CR::THREADS, 1) void image_kernel(const ImageParams
         // no barrier here: the next image is other memory, and every workgroup still arrives exactly once per barrier
     }
 }
+
+#endif  // MIFFT_EXPERIMENTAL
 
 // persistent grid: enough workgroups to fill every CU to its LDS / wave limit.  The formula ignores registers, so a kernel
 // that holds fewer workgroups than it launches leaves the surplus waiting for a slot; whether that hurts is kernel by kernel

@@ -21,6 +21,20 @@
  * (fft/fft/_fft.mojo:292-294), i.e. matches numpy.fft.fftn / ifftn over axes
  * 1..ndim.  A real input produces the FULL N-point spectrum
  * (fft/fft/_fft.mojo:254-257), not numpy's half spectrum.
+ *
+ * Environment (read ONCE per process, at the first plan; hackathon_fft_amd/csrc/mifft_config.h):
+ *     MIFFT_JIT=0           no runtime specialisation (hipRTC): lengths without a precompiled kernel run
+ *                           on the literal-stage kernels instead
+ *     MIFFT_JIT_CACHE_DIR   directory of the on-disk cache of runtime-specialised code objects (shared
+ *                           between processes / ranks; files are written atomically)
+ *     MIFFT_JIT_VERBOSE=1   say on stderr why a runtime specialisation failed
+ * Nothing else is configurable in libmifft.so: every size threshold of the plan-time policy is a
+ * constant derived from the 256-MiB Infinity Cache (kInfinityCacheBytes).  The measurement switches the
+ * scripts under tools/ use (MIFFT_ND_CACHE, MIFFT_NTS_*, MIFFT_FOURSTEP_*, MIFFT_FS_*, MIFFT_ROW2D,
+ * MIFFT_JIT_NT, MIFFT_JIT_IMAGE, MIFFT_DPP, MIFFT_GRID_PER_CU) and the fault injection of the tests
+ * (MIFFT_TEST_FAIL_SCRATCH_ALLOC) exist only in the LAB build, libmifft_lab.so
+ * (-DMIFFT_EXPERIMENTAL -DMIFFT_TESTING, same ABI), together with the experimental kernels that stayed
+ * negative results; the host package loads it only when MIFFT_LIBRARY points at it.
  */
 #ifndef MIFFT_H
 #define MIFFT_H
@@ -101,8 +115,11 @@ typedef struct mifft_plan mifft_plan;
  *  flags          MIFFT_FLAG_*.
  * The plan owns its device twiddle tables (a few KiB per dimension).  The reference's
  * plan always owns a scratch tensor of the output size (_ndim_fft_gpu.mojo:185); here
- * only two routes do -- query it with mifft_plan_scratch_bytes():
- *   - a STRIDED dimension longer than 4096 points (transpose -> rows -> transpose), and
+ * only three routes do -- query it with mifft_plan_scratch_bytes():
+ *   - a STRIDED dimension longer than 4096 points: the two-pass four-step through the scratch
+ *     (column tiles of N1 points out -> scratch with a row-granular transposition, column tiles of
+ *     N2 points scratch -> out), the default for such dimensions,
+ *   - its fallback when a factor has no fused column tile: transpose -> rows -> transpose, and
  *   - a contiguous dimension beyond one LDS row (> 16384 points) whose factorisation
  *     has no transposed-store kernel (the three-launch four-step).
  * Every other plan (all BASELINE configs) works without scratch: the contiguous

@@ -41,10 +41,12 @@ class _OracleBackend:
         self.plan = O.plan_fft(tn[in_dtype], tn[out_dtype], in_shape, out_shape, bases=bases, inverse=inverse,
                                default_target="gpu")
 
-    def run(self, out, x):
-        o = np.empty(tuple(out.shape), dtype=out.numpy().dtype)
-        self.O.fft(o, np.ascontiguousarray(x.numpy()), plan=self.plan, cpu_workers=1)
-        out.copy_(torch.from_numpy(o))
+    def run(self, out, x, first=0, count=None):
+        if count is None:
+            count = out.shape[0] - first
+        o = np.full(tuple(out.shape), np.nan, dtype=out.numpy().dtype)
+        self.O.fft(o, np.ascontiguousarray(x.numpy()), plan=self.plan, cpu_workers=1, first=first, count=count)
+        out[first:first + count].copy_(torch.from_numpy(o[first:first + count]))
 
 
 def _free_port():
@@ -91,6 +93,8 @@ def _worker(rank, world, port, shape, bases, q, loopback=False):
     (2, (5, 12, 10), None, False),
     (3, (10, 93), [[31, 3]], False),   # uneven 4,3,3
     (3, (2, 16), None, False),         # a rank with an empty slab
+    (2, (37, 32), None, False),        # 19 / 18 entries per rank: eight chunks of 3 / 2 entries in the pipeline
+    (3, (50, 20), None, False),        # 17 / 17 / 16
     (1, (3, 64), [[2]], True),         # one rank, its slab sent to itself through the process group
     (2, (5, 12, 10), None, True),      # the root's own slab takes the P2P path too
 ])

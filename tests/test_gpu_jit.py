@@ -250,25 +250,6 @@ def test_float_input_under_a_double_plan():
     assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F64
 
 
-@pytest.mark.parametrize("shape", [(20, 640, 480), (33, 256, 512)])
-def test_l2_resident_image_kernel_opt_in(shape, monkeypatch):
-    """MIFFT_JIT_IMAGE=1: every XCD transforms whole images -- rows x -> out, an XCD-local barrier (hardware XCC_ID,
-    relaxed agent-scope atomics in the shared L2), columns in place from L2.  Parity only: on MI355X the path is slower
-    than the two streaming passes and stays opt-in."""
-    monkeypatch.setenv("MIFFT_JIT_IMAGE", "1")
-    rng = np.random.default_rng(sum(shape))
-    x = rng.standard_normal(shape + (2,)).astype(np.float32)
-    out, plan = _run(x)
-    assert plan.kernel_name(1).startswith("image") and plan.num_launches == 1, plan.kernel_name(1)
-    assert plan.device_status() == 0           # no bounded spin expired, no surplus workgroup (sticky device flags)
-    truth = np.fft.fftn(to_complex(x), axes=(1, 2))
-    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
-    again, _ = _run(x)
-    assert np.array_equal(again, out)          # barrier counters are reset per launch; results are reproducible
-    back, _ = _run(out, inverse=True)
-    assert rel_l2(back, x) < REL_L2_TOL_F32
-
-
 _UNDER_PROFILER = r"""
 import sys, torch
 sys.path.insert(0, %(root)r)

@@ -617,50 +617,3 @@ def test_long_strided_dimension_four_step(shape):
     assert rel_l2(back, x) < REL_L2_TOL_F32
 
 
-@pytest.mark.parametrize("shape", [(1, 7680, 64), (2, 5000, 24), (1, 8192, 3, 5)])
-def test_long_strided_dimension_through_transposes(shape, monkeypatch):
-    """The fallback for such dimensions (MIFFT_FOURSTEP_STRIDED=0, or a factor without a fused column tile): the
-    reference's own route -- transpose -> row kernel -> transpose through the plan scratch."""
-    monkeypatch.setenv("MIFFT_FOURSTEP_STRIDED", "0")
-    rng = np.random.default_rng(sum(shape))
-    x = rng.standard_normal(shape + (2,)).astype(np.float32)
-    out, plan = gpu_fft(x, out_dtype=np.float32)
-    assert plan.kernel_name(0) == "transpose"
-    truth = np.fft.fftn(to_complex(x), axes=tuple(range(1, len(shape))))
-    assert rel_l2(out, from_complex(truth, np.float64)) < REL_L2_TOL_F32
-    back, _ = gpu_fft(out, inverse=True, out_dtype=np.float32)
-    assert rel_l2(back, x) < REL_L2_TOL_F32
-
-
-def test_scratch_allocation_failure_is_an_error_not_a_fallback(monkeypatch):
-    """A route that needs the plan scratch must report MIFFT_ERR_HIP when the device is out of memory -- not keep
-    half-built passes with a NULL scratch, and not hide the failure behind a slower kernel."""
-    monkeypatch.setenv("MIFFT_TEST_FAIL_SCRATCH_ALLOC", "1")
-    for fs in ("1", "0"):
-        monkeypatch.setenv("MIFFT_FOURSTEP_STRIDED", fs)
-        with pytest.raises(mf.MifftError) as e:
-            mf.plan_fft(torch.float32, torch.float32, (1, 7680, 64, 2), (1, 7680, 64, 2), ctx=mf.DeviceContext(0))
-        assert e.value.status == -11 and "device allocation" in e.value.message
-    monkeypatch.delenv("MIFFT_TEST_FAIL_SCRATCH_ALLOC")
-    monkeypatch.delenv("MIFFT_FOURSTEP_STRIDED")
-    plan = mf.plan_fft(torch.float32, torch.float32, (1, 7680, 64, 2), (1, 7680, 64, 2), ctx=mf.DeviceContext(0))
-    assert plan.scratch_bytes == 7680 * 64 * 8 and plan.num_launches == 3
-
-
-@pytest.mark.parametrize("shape,inverse", [((1, 93), False), ((16, 93), False), ((37, 93), False), ((301, 93), True),
-                                            ((3, 5, 93), False)])
-def test_dpp_radix3_rows(shape, inverse, monkeypatch):
-    """MIFFT_DPP=1: 93 = 31 * 3 with the radix-3 stage across three adjacent lanes through DPP row shifts (no LDS
-    exchange, no workgroup barrier; kernels_dpp.hip).  Opt-in because it measures slower than the tile kernel; the
-    arithmetic differs from the tile kernel's (one output per lane), so parity is against the oracle, and a slab must
-    still equal the same rows of the whole batch bit for bit."""
-    monkeypatch.setenv("MIFFT_DPP", "1")
-    rng = np.random.default_rng(sum(shape))
-    x = rng.standard_normal(shape + (2,)).astype(np.float32)
-    out, plan = gpu_fft(x, inverse=inverse, out_dtype=np.float32)
-    assert plan.kernel_name(len(shape) - 2).startswith("rows93_31x3_dpp")
-    assert not np.isnan(out).any()
-    assert rel_l2(out, O.fftn(x, inverse=inverse)) < REL_L2_TOL_F32
-    if shape[0] >= 16:
-        part, _ = gpu_fft(x, inverse=inverse, out_dtype=np.float32, first=5, count=7)
-        assert np.array_equal(part[5:12], out[5:12]) and np.isnan(part[:5]).all() and np.isnan(part[12:]).all()

@@ -18,7 +18,7 @@ for o in "${objs[@]}"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function "${flags[@]}" "${x[@]}" -c $src/$o.$ext -o build_alt/$tag/$o.o
 done
 all=()
-for f in mifft_api planner kernels_jit kernels_generic kernels_fast kernels_dpp kernels_fourstep kernels_fast_gen_rows kernels_fast_gen_cols kernels_fast_gen_rows_f64 kernels_fast_gen_cols_f64; do
+for f in mifft_api planner kernels_jit kernels_generic kernels_fast kernels_fourstep kernels_fast_gen_rows kernels_fast_gen_cols kernels_fast_gen_rows_f64 kernels_fast_gen_cols_f64; do
   if [ -f build_alt/$tag/$f.o ]; then all+=(build_alt/$tag/$f.o); else all+=($src/$f.o); fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_alt/$tag/libmifft.so "${all[@]}" -L/opt/rocm/lib -lhiprtc

@@ -1,6 +1,7 @@
 """Strided four-step against the single column tile for strided dimensions of 1024..4096 points
 (MIFFT_FS_STRIDED_MIN_N, tuning knob).   python tools/fs_minn_probe.py"""
 import os
+os.environ.setdefault("MIFFT_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hackathon_fft_amd", "csrc", "libmifft_lab.so"))  # the MIFFT_* switches below exist in the lab build only
 import subprocess
 import sys
 

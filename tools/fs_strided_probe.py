@@ -3,6 +3,7 @@
 planner's own (most balanced) choice and the transposed route.   python tools/fs_strided_probe.py [workload]"""
 import json
 import os
+os.environ.setdefault("MIFFT_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hackathon_fft_amd", "csrc", "libmifft_lab.so"))  # the MIFFT_* switches below exist in the lab build only
 import subprocess
 import sys
 

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Workgroups per CU of the persistent grid, per table kernel: times bench workloads with MIFFT_GRID_PER_CU = 0 (formula),
-1..8 on a -DMIFFT_EXPERIMENTAL build of the library (tools/ab_build.sh lab -DMIFFT_EXPERIMENTAL), interleaved on one box.
+1..8 on the lab build of the library (hackathon_fft_amd/csrc/libmifft_lab.so), interleaved on one box.
     python tools/grid_sweep.py [workload ...]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = os.path.join(ROOT, "build_alt", "lab", "libmifft.so")
+lib = os.path.join(ROOT, "hackathon_fft_amd", "csrc", "libmifft_lab.so")
 wl = sys.argv[1:] or ["1d_100kx1024_radix2", "1d_500kx128", "1d_500kx93_radix31x3", "2d_100x640x480", "3d_10x128x128x128"]
 for w in wl:
     row = []

@@ -3,6 +3,7 @@
 batches of 128^3 volumes (16.8 MB each) and of 640 x 480 images (2.46 MB each), time per unit as the tensor grows past
 the cache, with the cache policy on (MIFFT_ND_CACHE=3, default) and off (0).   python tools/ic_footprint_probe.py"""
 import os
+os.environ.setdefault("MIFFT_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hackathon_fft_amd", "csrc", "libmifft_lab.so"))  # the MIFFT_* switches below exist in the lab build only
 import subprocess
 import sys
 

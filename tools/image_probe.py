@@ -1,6 +1,7 @@
 """L2-resident image kernel (rows, XCD-local barrier, columns from L2) against separate row and column passes
 (default).  GPU box:  MIFFT_JIT_IMAGE=1 python tools/image_probe.py ; python tools/image_probe.py"""
 import os, sys
+os.environ.setdefault("MIFFT_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hackathon_fft_amd", "csrc", "libmifft_lab.so"))  # the MIFFT_* switches below exist in the lab build only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

@@ -8,6 +8,7 @@ the first pass, 2 in-place passes walk their tiles in alternating directions, 3 
 import hashlib
 import json
 import os
+os.environ.setdefault("MIFFT_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hackathon_fft_amd", "csrc", "libmifft_lab.so"))  # the MIFFT_* switches below exist in the lab build only
 import subprocess
 import sys
 

@@ -1,6 +1,7 @@
 """The N-D cache policy (MIFFT_ND_CACHE) at three tensor sizes per shape family: fully cache-resident,
 around the cache size, beyond it.   python tools/nd_size_probe.py"""
 import os
+os.environ.setdefault("MIFFT_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hackathon_fft_amd", "csrc", "libmifft_lab.so"))  # the MIFFT_* switches below exist in the lab build only
 import subprocess
 import sys
 

@@ -2,6 +2,7 @@
 MIFFT_JIT_NT=0 (plain kernels), default (runtime-specialised lengths store non-temporally above ~0.1 GB), MIFFT_JIT_NT=2
 (lengths of the generated table too, through the runtime-specialised twin).   python tools/nts_probe.py"""
 import os
+os.environ.setdefault("MIFFT_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hackathon_fft_amd", "csrc", "libmifft_lab.so"))  # the MIFFT_* switches below exist in the lab build only
 import subprocess
 import sys
 

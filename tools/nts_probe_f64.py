@@ -1,6 +1,7 @@
 """fp64 side of tools/nts_probe.py: the non-temporal-store window on (default) and off (MIFFT_NTS_MIN_BYTES=1e18,
 MIFFT_JIT_NT=0).   python tools/nts_probe_f64.py"""
 import os
+os.environ.setdefault("MIFFT_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hackathon_fft_amd", "csrc", "libmifft_lab.so"))  # the MIFFT_* switches below exist in the lab build only
 import subprocess
 import sys
 

@@ -1,6 +1,7 @@
 """2-D plans whose only pass is a fused plane: non-temporal stores in the 0.25-0.65 GB window (default) against
 plain stores (MIFFT_NTS_MIN_BYTES=1e18 MIFFT_JIT_NT=0).   python tools/plane_nts_probe.py"""
 import os
+os.environ.setdefault("MIFFT_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hackathon_fft_amd", "csrc", "libmifft_lab.so"))  # the MIFFT_* switches below exist in the lab build only
 import subprocess
 import sys
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MIFFT_LIBRARY=${MIFFT_LIBRARY:-$PWD/hackathon_fft_amd/csrc/libmifft_lab.so}  # MIFFT_ND_CACHE is a lab-build switch
 # round-2 measurement batch 1 (GPU box)
 set -o pipefail
 root=${GRAFT_REPO_ROOT:-$(pwd)}

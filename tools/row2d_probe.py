@@ -1,6 +1,7 @@
 """16384-point rows: the four-step inside one LDS plane (default) against MIFFT_ROW2D=0 (one workgroup per row with the
 global twiddle table, or two column-tile launches for big batches).   python tools/row2d_probe.py"""
 import os
+os.environ.setdefault("MIFFT_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hackathon_fft_amd", "csrc", "libmifft_lab.so"))  # the MIFFT_* switches below exist in the lab build only
 import subprocess
 import sys
 
