@@ -24,7 +24,13 @@ import torch
 from . import _lib
 from ._lib import MifftError, check
 
-_DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.uint8: 2, torch.int32: 3}
+# mifft_dtype (include/mifft.h).  Input tensors may have any of these element types -- the reference casts in its
+# first-stage load (fft/fft/_fft.mojo:243-257); the output is float32 or float64.
+_DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.uint8: 2, torch.int32: 3, torch.int8: 4, torch.int16: 5,
+               torch.float16: 7, torch.bfloat16: 8}
+if hasattr(torch, "uint16"):
+    _DTYPE_CODE[torch.uint16] = 6
+_OUT_DTYPES = (torch.float32, torch.float64)
 
 FLAG_FAITHFUL_STAGES = 1
 
@@ -113,8 +119,8 @@ class Plan:
                  device: int = 0, flags: int = 0, whole_batch: int = 0):
         in_shape, out_shape = tuple(int(v) for v in in_shape), tuple(int(v) for v in out_shape)
         _check_layout_conditions_nd(in_shape, out_shape)
-        if in_dtype not in _DTYPE_CODE or out_dtype not in _DTYPE_CODE:
-            raise MifftError(-4, f"unsupported dtype {in_dtype} -> {out_dtype}")
+        if in_dtype not in _DTYPE_CODE or out_dtype not in _OUT_DTYPES:
+            raise MifftError(-4, f"unsupported dtype {in_dtype} -> {out_dtype} (out_dtype must be floating point)")
         dims = out_shape[1:-1]
         if bases is not None and len(bases) != len(dims):
             raise MifftError(-7, "The bases list should have the same outer size as the amount of internal "

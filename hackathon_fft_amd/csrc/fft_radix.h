@@ -36,6 +36,12 @@ struct alignas(2 * sizeof(T)) cpx {
     T x, y;
 };
 
+// bfloat16 as an INPUT element type (MIFFT_BF16): the upper half of a binary32, widened exactly
+struct bf16_t {
+    unsigned short bits;
+    MIFFT_DEV operator float() const { return __builtin_bit_cast(float, (unsigned)bits << 16); }
+};
+
 template <typename T> MIFFT_DEV cpx<T> operator+(cpx<T> a, cpx<T> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename T> MIFFT_DEV cpx<T> operator-(cpx<T> a, cpx<T> b) { return {a.x - b.x, a.y - b.y}; }
 template <typename T> MIFFT_DEV cpx<T> cmul(cpx<T> a, cpx<T> b) {

@@ -19,6 +19,7 @@
 // Specialised register-butterfly kernels (kernels_fast_*.hip) take over the
 // BASELINE shapes; this family is the general fallback and the
 // MIFFT_FLAG_FAITHFUL_STAGES path.
+#include "fft_radix.h"  // bf16_t
 #include "mifft_internal.h"
 
 namespace mifft {
@@ -58,17 +59,27 @@ __device__ __forceinline__ V cfma(V w, V x, V c) {
     return r;
 }
 
+template <typename T, typename TIn>
+__device__ __forceinline__ T cast_in(TIn v) {
+    return (T)v;
+}
+template <typename T>
+__device__ __forceinline__ T cast_in(bf16_t v) {
+    return (T)(float)v;
+}
+
 // first-stage load with dtype cast and real->complex promotion (fft/fft/_fft.mojo:254-257)
 template <typename T, typename TIn, int COMPS>
 __device__ __forceinline__ typename C2<T>::type load_in(const void* base, long long g) {
     typename C2<T>::type v;
     const TIn* p = (const TIn*)base;
+    // (float) first: exact for every element type narrower than T (and the only conversion bf16_t offers)
     if (COMPS == 1) {
-        v.x = (T)p[g];
+        v.x = cast_in<T>(p[g]);
         v.y = (T)0;
     } else {
-        v.x = (T)p[2 * g];
-        v.y = (T)p[2 * g + 1];
+        v.x = cast_in<T>(p[2 * g]);
+        v.y = cast_in<T>(p[2 * g + 1]);
     }
     return v;
 }
@@ -201,6 +212,21 @@ static hipError_t launch_first(const Plan& plan, const GenericParams& gp, int gr
         case MIFFT_I32:
             return c == 1 ? launch_one<T, int, 1, true>(gp, grid, threads, lds, s, prep)
                           : launch_one<T, int, 2, true>(gp, grid, threads, lds, s, prep);
+        case MIFFT_I8:
+            return c == 1 ? launch_one<T, signed char, 1, true>(gp, grid, threads, lds, s, prep)
+                          : launch_one<T, signed char, 2, true>(gp, grid, threads, lds, s, prep);
+        case MIFFT_I16:
+            return c == 1 ? launch_one<T, short, 1, true>(gp, grid, threads, lds, s, prep)
+                          : launch_one<T, short, 2, true>(gp, grid, threads, lds, s, prep);
+        case MIFFT_U16:
+            return c == 1 ? launch_one<T, unsigned short, 1, true>(gp, grid, threads, lds, s, prep)
+                          : launch_one<T, unsigned short, 2, true>(gp, grid, threads, lds, s, prep);
+        case MIFFT_F16:
+            return c == 1 ? launch_one<T, _Float16, 1, true>(gp, grid, threads, lds, s, prep)
+                          : launch_one<T, _Float16, 2, true>(gp, grid, threads, lds, s, prep);
+        case MIFFT_BF16:
+            return c == 1 ? launch_one<T, bf16_t, 1, true>(gp, grid, threads, lds, s, prep)
+                          : launch_one<T, bf16_t, 2, true>(gp, grid, threads, lds, s, prep);
     }
     return hipErrorInvalidValue;
 }

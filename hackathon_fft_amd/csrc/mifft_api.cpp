@@ -189,7 +189,7 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
         return set_error(MIFFT_ERR_BAD_COMPONENTS, "The last dimension of in_layout should be 1 or 2");
     if (out_dtype != MIFFT_F32 && out_dtype != MIFFT_F64)
         return set_error(MIFFT_ERR_BAD_DTYPE, "out_dtype must be floating point");
-    if (in_dtype < MIFFT_F32 || in_dtype > MIFFT_I32) return set_error(MIFFT_ERR_BAD_DTYPE, "unsupported in_dtype");
+    if (dtype_size(in_dtype) == 0) return set_error(MIFFT_ERR_BAD_DTYPE, "unsupported in_dtype");
     if (batch < 0) return set_error(MIFFT_ERR_BAD_BATCH, "batch must be >= 0");
     for (int i = 0; i < ndim; ++i)
         if (dims[i] < 2) return set_error(MIFFT_ERR_BAD_DIM, "no inner dimension should be of size 1");

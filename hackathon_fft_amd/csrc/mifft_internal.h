@@ -147,6 +147,11 @@ inline size_t dtype_size(int dt) {
         case MIFFT_F64: return 8;
         case MIFFT_U8: return 1;
         case MIFFT_I32: return 4;
+        case MIFFT_I8: return 1;
+        case MIFFT_I16: return 2;
+        case MIFFT_U16: return 2;
+        case MIFFT_F16: return 2;
+        case MIFFT_BF16: return 2;
     }
     return 0;
 }

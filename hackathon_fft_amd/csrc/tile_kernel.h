@@ -73,19 +73,25 @@ MIFFT_DEV void gstore(cpx<T>* p, cpx<T> v) {
 template <class A, class B> struct same_t { static constexpr bool value = false; };
 template <class A> struct same_t<A, A> { static constexpr bool value = true; };
 
-// one input element of a FOREIGN element type IT (uint8 / int32 / float under a double plan), real or interleaved
-// complex, widened to cpx<T>
+// one input element of a FOREIGN element type IT (uint8 / int8 / int16 / uint16 / int32 / half / bfloat16, or float under a
+// double plan), real or interleaved complex, widened to cpx<T> -- the reference's `x.load(...).cast[out_dtype]()`,
+// fft/fft/_fft.mojo:243-257
 template <class C>
 MIFFT_DEV cpx<typename C::T> load_foreign(const void* in, long long idx) {
     using T = typename C::T;
     using IT = typename C::IT;
     const IT* p = (const IT*)in;
+    // through float for bf16_t (its only conversion); exact for every element type narrower than T
+    auto widen = [](IT v) -> T {
+        if constexpr (same_t<IT, bf16_t>::value) return (T)(float)v;
+        else return (T)v;
+    };
     if constexpr (C::IN_REAL) {
-        return {(T)p[idx], (T)0};
+        return {widen(p[idx]), (T)0};
     } else {
         struct alignas(2 * sizeof(IT)) pair_t { IT re, im; };
         const pair_t v = ((const pair_t*)p)[idx];
-        return {(T)v.re, (T)v.im};
+        return {widen(v.re), widen(v.im)};
     }
 }
 

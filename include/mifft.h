@@ -58,7 +58,14 @@ typedef enum {
     MIFFT_F32 = 0,
     MIFFT_F64 = 1,
     MIFFT_U8 = 2, /* reference 2-D/3-D tests feed uint8: fft/tests.mojo:467,524 */
-    MIFFT_I32 = 3
+    MIFFT_I32 = 3,
+    /* the reference casts ANY element type in its first-stage load (`x.load(...).cast[out_dtype]()`,
+     * fft/fft/_fft.mojo:243-257); these are widened to the plan's out_dtype in the first pass the same way: */
+    MIFFT_I8 = 4,
+    MIFFT_I16 = 5,
+    MIFFT_U16 = 6,
+    MIFFT_F16 = 7,  /* IEEE binary16 */
+    MIFFT_BF16 = 8  /* bfloat16: the upper 16 bits of a binary32 */
 } mifft_dtype;
 
 /* error codes; the reference raises these as compile-time asserts

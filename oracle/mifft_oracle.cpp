@@ -36,7 +36,46 @@
 
 // Same numeric values as include/mifft.h (kept literal so the oracle has no
 // build dependency on the product tree).
-enum { ORA_F32 = 0, ORA_F64 = 1, ORA_U8 = 2, ORA_I32 = 3 };
+enum { ORA_F32 = 0, ORA_F64 = 1, ORA_U8 = 2, ORA_I32 = 3, ORA_I8 = 4, ORA_I16 = 5, ORA_U16 = 6, ORA_F16 = 7, ORA_BF16 = 8 };
+
+// 16-bit floating inputs as storage types: the reference's `x.load(...).cast[out_dtype]()` (fft/fft/_fft.mojo:243-257)
+// widens them exactly; g++ 11 has no _Float16 in C++, so the IEEE binary16 -> binary32 conversion is spelled out.
+struct F16In {
+    uint16_t b;
+    operator float() const {
+        const uint32_t sign = (uint32_t)(b & 0x8000u) << 16, e = (b >> 10) & 0x1Fu, m = b & 0x3FFu;
+        uint32_t u;
+        if (e == 0) {
+            if (m == 0) {
+                u = sign;
+            } else {  // subnormal: normalise
+                int sh = 0;
+                uint32_t mm = m;
+                while (!(mm & 0x400u)) {
+                    mm <<= 1;
+                    ++sh;
+                }
+                u = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((mm & 0x3FFu) << 13);
+            }
+        } else if (e == 31) {
+            u = sign | 0x7F800000u | (m << 13);
+        } else {
+            u = sign | ((e + 127 - 15) << 23) | (m << 13);
+        }
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    }
+};
+struct BF16In {
+    uint16_t b;
+    operator float() const {
+        const uint32_t u = (uint32_t)b << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    }
+};
 enum {
     ORA_OK = 0,
     ORA_ERR_BAD_RANK = -1,
@@ -350,9 +389,15 @@ static void build_dimplan(DimPlan<T>& dp, int64_t N, const std::vector<uint64_t>
 // ---------------------------------------------------------------------------
 
 template <typename T, typename TIn>
+static inline T cast_in(TIn v) {
+    if constexpr (std::is_same<TIn, F16In>::value || std::is_same<TIn, BF16In>::value) return (T)(float)v;
+    else return (T)v;
+}
+
+template <typename T, typename TIn>
 static inline Cx<T> load_x(const TIn* x, int64_t idx, int comps) {
-    if (comps == 1) return {(T)x[idx], (T)0};        // _fft.mojo:254-255
-    return {(T)x[2 * idx], (T)x[2 * idx + 1]};        // _fft.mojo:257
+    if (comps == 1) return {cast_in<T>(x[idx]), (T)0};                   // _fft.mojo:254-255
+    return {cast_in<T>(x[2 * idx]), cast_in<T>(x[2 * idx + 1])};          // _fft.mojo:257
 }
 
 // MODE: 0 large N (runtime twiddle table, plain complex FMA), 1 N <= 128 (strength-reduced phasors), 2 N <= 128 real
@@ -567,6 +612,11 @@ static int dispatch_in(OraclePlan& pl, void* out, const void* x, int64_t first, 
         case ORA_F64: run_nd<T, double>(pl, (Cx<T>*)out, (const double*)x, first, count, workers); break;
         case ORA_U8: run_nd<T, uint8_t>(pl, (Cx<T>*)out, (const uint8_t*)x, first, count, workers); break;
         case ORA_I32: run_nd<T, int32_t>(pl, (Cx<T>*)out, (const int32_t*)x, first, count, workers); break;
+        case ORA_I8: run_nd<T, int8_t>(pl, (Cx<T>*)out, (const int8_t*)x, first, count, workers); break;
+        case ORA_I16: run_nd<T, int16_t>(pl, (Cx<T>*)out, (const int16_t*)x, first, count, workers); break;
+        case ORA_U16: run_nd<T, uint16_t>(pl, (Cx<T>*)out, (const uint16_t*)x, first, count, workers); break;
+        case ORA_F16: run_nd<T, F16In>(pl, (Cx<T>*)out, (const F16In*)x, first, count, workers); break;
+        case ORA_BF16: run_nd<T, BF16In>(pl, (Cx<T>*)out, (const BF16In*)x, first, count, workers); break;
         default: return fail(ORA_ERR_BAD_DTYPE, "unsupported in_dtype");
     }
     return ORA_OK;
@@ -603,7 +653,7 @@ int mifft_oracle_plan_create(void** out_plan, int in_dtype, int out_dtype, int n
     if (in_components < 1 || in_components > 2)
         return fail(ORA_ERR_BAD_COMPONENTS, "The last dimension of in_layout should be 1 or 2");
     if (out_dtype != ORA_F32 && out_dtype != ORA_F64) return fail(ORA_ERR_BAD_DTYPE, "out_dtype must be floating point");
-    if (in_dtype < ORA_F32 || in_dtype > ORA_I32) return fail(ORA_ERR_BAD_DTYPE, "unsupported in_dtype");
+    if (in_dtype < ORA_F32 || in_dtype > ORA_BF16) return fail(ORA_ERR_BAD_DTYPE, "unsupported in_dtype");
     if (batch < 0) return fail(ORA_ERR_BAD_BATCH, "batch < 0");
     for (int i = 0; i < ndim; ++i)
         if (dims[i] < 2) return fail(ORA_ERR_BAD_DIM, "no inner dimension should be of size 1");

@@ -19,7 +19,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmifft_oracle.so")
 
-_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.int32): 3}
+_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.int32): 3,
+           np.dtype(np.int8): 4, np.dtype(np.int16): 5, np.dtype(np.uint16): 6, np.dtype(np.float16): 7}
+BF16 = "bfloat16"  # pass in_dtype=BF16 with a uint16 array of bfloat16 bit patterns (numpy has no bfloat16)
 
 
 def build(force: bool = False) -> str:
@@ -99,7 +101,8 @@ class OraclePlan:
             raise OracleError(-3, "out_layout must have the last dimension equal to 2")
         if in_shape[:-1] != out_shape[:-1]:
             raise OracleError(-2, "out_layout and in_layout should have the same shape before the last dimension")
-        self.in_dtype, self.out_dtype = np.dtype(in_dtype), np.dtype(out_dtype)
+        self.bf16 = isinstance(in_dtype, str) and in_dtype == BF16
+        self.in_dtype, self.out_dtype = np.dtype(np.uint16 if self.bf16 else in_dtype), np.dtype(out_dtype)
         self.in_shape, self.out_shape = in_shape, out_shape
         self.inverse = bool(inverse)
         dims = out_shape[1:-1]
@@ -115,7 +118,7 @@ class OraclePlan:
         h = ctypes.c_void_p()
         if self.in_dtype not in _DTYPES or self.out_dtype not in _DTYPES:
             raise OracleError(-4, "unsupported dtype")
-        rc = lib().mifft_oracle_plan_create(ctypes.byref(h), _DTYPES[self.in_dtype], _DTYPES[self.out_dtype],
+        rc = lib().mifft_oracle_plan_create(ctypes.byref(h), 8 if self.bf16 else _DTYPES[self.in_dtype], _DTYPES[self.out_dtype],
                                             len(dims), c_dims, out_shape[0], in_shape[-1], int(self.inverse),
                                             c_flat, c_len, 1 if default_target == "gpu" else 0)
         _check(rc)
@@ -151,8 +154,9 @@ def fft(output: np.ndarray, x: np.ndarray, *, plan: OraclePlan, cpu_workers: Opt
     _check(rc)
 
 
-def fftn(x: np.ndarray, *, inverse=False, bases=None, out_dtype=None, cpu_workers=None) -> np.ndarray:
-    """Convenience: x is (batch, d0.., C) real-typed, or complex (batch, d0..)."""
+def fftn(x: np.ndarray, *, inverse=False, bases=None, out_dtype=None, cpu_workers=None, in_dtype=None) -> np.ndarray:
+    """Convenience: x is (batch, d0.., C) real-typed, or complex (batch, d0..).  ``in_dtype=BF16``: x holds bfloat16 bit
+    patterns as uint16."""
     if np.iscomplexobj(x):
         x = np.ascontiguousarray(x)
         x = x.view(x.real.dtype).reshape(x.shape + (2,))
@@ -160,7 +164,7 @@ def fftn(x: np.ndarray, *, inverse=False, bases=None, out_dtype=None, cpu_worker
     if out_dtype is None:
         out_dtype = x.dtype if x.dtype in (np.float32, np.float64) else np.float64
     out_shape = x.shape[:-1] + (2,)
-    plan = plan_fft(x.dtype, out_dtype, x.shape, out_shape, inverse=inverse, bases=bases)
+    plan = plan_fft(in_dtype if in_dtype is not None else x.dtype, out_dtype, x.shape, out_shape, inverse=inverse, bases=bases)
     out = np.full(out_shape, np.nan, dtype=out_dtype)
     fft(out, x, plan=plan, cpu_workers=cpu_workers)
     return out

@@ -116,6 +116,9 @@ def test_jit_precompile_needs_no_device():
     assert L.mifft_jit_precompile(1, 1, 121, 0, 0, ctypes.byref(sz)) == 0  # fp64
     assert L.mifft_jit_precompile(2, 0, 480, 0, 1, ctypes.byref(sz)) == 0  # uint8 real input widened in the load
     assert L.mifft_jit_precompile(3, 0, 96, 0, 0, ctypes.byref(sz)) == 0   # int32 complex input
+    for code in (4, 5, 6, 7, 8):                                           # int8 / int16 / uint16 / half / bfloat16
+        assert L.mifft_jit_precompile(code, 0, 96, 0, code % 2, ctypes.byref(sz)) == 0, code
+    assert L.mifft_jit_precompile(9, 0, 96, 0, 0, ctypes.byref(sz)) == -4   # no such element type
     assert L.mifft_jit_precompile(0, 1, 93, 0, 0, ctypes.byref(sz)) == 0   # float input under a double plan
     assert L.mifft_jit_precompile(0, 0, 97, 0, 0, ctypes.byref(sz)) == 0    # one prime factor <= 4093: cooperative pass 0
     assert L.mifft_jit_precompile(0, 0, 4099, 0, 0, ctypes.byref(sz)) == -9

@@ -163,6 +163,53 @@ def test_input_dtypes_and_real_input(in_dtype, comps):
     assert rel_l2(out, ref) < REL_L2_TOL_F32
 
 
+def _narrow_input(kind, shape, seed):
+    """(torch tensor on the CPU, numpy array for the oracle, oracle in_dtype or None, float64 values)"""
+    rng = np.random.default_rng(seed)
+    if kind == "bfloat16":
+        t = torch.from_numpy(rng.standard_normal(shape).astype(np.float32) * 8).to(torch.bfloat16)
+        return t, t.view(torch.int16).numpy().view(np.uint16), O.BF16, t.to(torch.float64).numpy()
+    if kind == "float16":
+        a = (rng.standard_normal(shape) * 8).astype(np.float16)
+    elif kind == "int8":
+        a = rng.integers(-128, 128, size=shape).astype(np.int8)
+    elif kind == "int16":
+        a = rng.integers(-32768, 32768, size=shape).astype(np.int16)
+    else:
+        a = rng.integers(0, 65536, size=shape).astype(np.uint16)
+    return torch.from_numpy(a), a, None, a.astype(np.float64)
+
+
+@pytest.mark.parametrize("kind", ["int8", "int16", "uint16", "float16", "bfloat16"])
+@pytest.mark.parametrize("comps", [1, 2])
+@pytest.mark.parametrize("shape,faithful", [((5, 96), False), ((3, 1024), False), ((2, 24, 20), False), ((2, 6, 4, 8), False),
+                                            ((3, 60), True)])
+def test_every_input_element_type_the_reference_casts(kind, comps, shape, faithful):
+    """The reference widens ANY element type in its first-stage load (`x.load(...).cast[out_dtype]()`,
+    fft/fft/_fft.mojo:243-257; its own tests feed uint8).  int8 / int16 / uint16 / half / bfloat16, real and complex,
+    through the runtime-specialised first pass (and the literal stages with faithful=True), against the oracle with the
+    same casts and against fp64 pocketfft on the exactly widened values."""
+    if kind == "uint16" and not hasattr(torch, "uint16"):
+        pytest.skip("this torch has no uint16")
+    t, a, ora_dtype, vals = _narrow_input(kind, shape + (comps,), seed=len(kind) + comps + sum(shape))
+    for odt, tol in ((torch.float32, REL_L2_TOL_F32), (torch.float64, REL_L2_TOL_F64)):
+        x = t.to(DEV)
+        out = torch.full(shape + (2,), float("nan"), dtype=odt, device=DEV)
+        with mf.DeviceContext(0) as ctx:
+            plan = mf.plan_fft(x.dtype, odt, tuple(x.shape), tuple(out.shape), faithful_stages=faithful, ctx=ctx)
+            mf.fft(out, x, ctx, plan=plan)
+            ctx.synchronize()
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any()
+        ndt = np.float32 if odt == torch.float32 else np.float64
+        assert rel_l2(got, O.fftn(a, out_dtype=ndt, in_dtype=ora_dtype)) < tol, plan.kernel_name(len(shape) - 2)
+        z = vals[..., 0] + (1j * vals[..., 1] if comps == 2 else 0)
+        truth = np.fft.fftn(z, axes=tuple(range(1, len(shape))))
+        assert rel_l2(got, from_complex(truth, np.float64)) < (REL_L2_TOL_F32 if odt == torch.float32 else 1e-11)
+        if not faithful:
+            assert "_jit" in plan.kernel_name(len(shape) - 2), plan.kernel_name(len(shape) - 2)
+
+
 def test_batch_range_and_untouched_rows():
     rng = np.random.default_rng(11)
     x = rng.standard_normal((10, 1024, 2)).astype(np.float32)

@@ -108,3 +108,41 @@ def test_every_output_element_written_and_x_untouched():
     out2 = np.full(x.shape, np.nan)
     O.fft(out2, x, plan=plan, first=1, count=1)
     assert np.isnan(out2[0]).all() and np.isnan(out2[2]).all() and np.array_equal(out2[1], out[1])
+
+
+@pytest.mark.parametrize("kind", ["int8", "int16", "uint16", "float16", "bfloat16"])
+@pytest.mark.parametrize("comps", [1, 2])
+def test_oracle_widens_narrow_input_types_exactly(kind, comps):
+    """`x.load(...).cast[out_dtype]()` (fft/fft/_fft.mojo:243-257) for the element types the GPU path accepts beyond the
+    reference's own uint8 tests: the oracle's result on the narrow tensor equals its result on the same values held in
+    float64 (every such value is exact in float64), bit for bit."""
+    rng = np.random.default_rng(len(kind) + comps)
+    shape = (3, 12, 10, comps)
+    in_dtype = None
+    if kind == "bfloat16":
+        f = rng.standard_normal(shape).astype(np.float32)
+        bits = (f.view(np.uint32) >> 16).astype(np.uint16)          # truncate to bfloat16
+        vals = (bits.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        a, in_dtype = bits, O.BF16
+    elif kind == "float16":
+        a = (rng.standard_normal(shape) * 4).astype(np.float16)
+        vals = a.astype(np.float64)
+    else:
+        info = np.iinfo(kind)
+        a = rng.integers(info.min, info.max + 1, size=shape).astype(kind)
+        vals = a.astype(np.float64)
+    got = O.fftn(a, out_dtype=np.float64, in_dtype=in_dtype)
+    want = O.fftn(vals, out_dtype=np.float64)
+    assert np.array_equal(got, want)
+    z = vals[..., 0] + (1j * vals[..., 1] if comps == 2 else 0)
+    truth = np.fft.fftn(z, axes=(1, 2))
+    assert np.abs(got[..., 0] + 1j * got[..., 1] - truth).max() <= 1e-11 * np.abs(truth).max()
+
+
+def test_oracle_half_conversion_is_exact_for_every_finite_value():
+    h = np.arange(0, 65536, dtype=np.uint16).view(np.float16)
+    h = h[np.isfinite(h.astype(np.float32))]
+    x = h[:len(h) // 2 * 2].reshape(-1, 2, 1)
+    y = O.fftn(x, out_dtype=np.float64)          # 2-point DFT of (a, b): (a + b, a - b), exact in float64
+    a, b = x[:, 0, 0].astype(np.float64), x[:, 1, 0].astype(np.float64)
+    assert np.array_equal(y[:, 0, 0], a + b) and np.array_equal(y[:, 1, 0], a - b)
