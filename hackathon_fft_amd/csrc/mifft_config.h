@@ -43,6 +43,13 @@ struct Config {
     long long fourstep_min_n = 16384;
     double fourstep_min_bytes = 0.119 * kInfinityCacheBytes;  // 32 MB of output
 
+    // prime radices above 32 run in LDS: as Rader's cyclic convolution when R - 1 splits into register butterflies and
+    // R >= rader_min (cooperative conjugate-pair pass otherwise).  Per 128 MB, cooperative -> Rader (tools/big_prime_probe2.py):
+    // R = 37 0.082 -> 0.069 ms, 97 0.152 -> 0.078, 131 0.200 -> 0.108, 251 0.307 -> 0.124, 1009 1.06 -> 0.17, 4093 4.26 -> 0.30;
+    // a length with TWO such primes (1517 = 41 * 37: 0.151 -> 0.186) keeps the cooperative pass below rader_min_pair.
+    int rader_min = 33;
+    int rader_min_pair = 128;
+
     // ---- Infinity-Cache policy of N-D schedules: bit 0 non-temporal first pass, bit 1 alternating walk ----
     int nd_mode = 3;
 
@@ -55,6 +62,7 @@ struct Config {
     bool jit_image = false;          // L2-resident image kernel (negative result, DESIGN_EXPERIMENTS.md)
     bool dpp = false;                // wave-shuffle radix-3 kernel for N = 93 (negative result)
     int grid_per_cu = 0;             // forces the persistent grid of every table kernel (tools/grid_sweep.py)
+    std::string jit_defines;         // extra -D options for the runtime compiler (A/B of kernel-header macros)
     bool test_fail_scratch_alloc = false;  // -DMIFFT_TESTING: the next scratch allocation reports out-of-memory
 };
 
@@ -82,6 +90,8 @@ inline Config load_config() {
     if (const char* v = env("MIFFT_JIT_IMAGE")) c.jit_image = v[0] == '1';
     if (const char* v = env("MIFFT_DPP")) c.dpp = v[0] == '1';
     if (const char* v = env("MIFFT_GRID_PER_CU")) c.grid_per_cu = atoi(v);
+    if (const char* v = env("MIFFT_JIT_DEFINES")) c.jit_defines = v;
+    if (const char* v = env("MIFFT_RADER_MIN")) c.rader_min = c.rader_min_pair = atoi(v);
 #endif
 #ifdef MIFFT_TESTING
     if (const char* v = env("MIFFT_TEST_FAIL_SCRATCH_ALLOC")) c.test_fail_scratch_alloc = v[0] == '1';

@@ -33,6 +33,11 @@
 
 #include "fft_radix.h"
 
+// cooperative prime pass (bigprime_pass): consecutive output pairs per thread (each input pair is read once per SB outputs)
+#ifndef MIFFT_BIGP_SB
+#define MIFFT_BIGP_SB 4
+#endif
+
 // odd prime radices from this size on use the emit-as-you-go butterfly in LDS-bound passes (pass_compute_scatter)
 #ifndef MIFFT_EMIT_PRIME_MIN
 #define MIFFT_EMIT_PRIME_MIN 17
@@ -130,10 +135,59 @@ constexpr bool is_pow2_ce(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
 
+// ---- Rader: a prime radix R too large for a register butterfly (R > 32) as a cyclic convolution of length M = R - 1 ----
+// x[g^q] (*) W_R^(g^-q), computed with an M-point FFT, a pointwise product with the precomputed spectrum of the kernel and
+// an inverse M-point FFT, all inside the LDS tile (rader_pass).  2 * 5 M log2 M flops per R-point DFT instead of the 4 (R/2)^2
+// FMAs of the cooperative conjugate-pair pass (bigprime_pass): 3x fewer at R = 97, 20x at R = 1009.  Applicable when
+// M = R - 1 splits into at most four register butterflies (factors <= 16, or one prime <= 31 each): rader_ok, evaluated by
+// the host, which selects the pass per configuration (TileCfg::RADERM) and uploads its tables.
+struct RaderSplitT {
+    int np;
+    int r[4];
+    bool ok;
+};
+constexpr RaderSplitT rader_split(int M) {
+    RaderSplitT s{0, {1, 1, 1, 1}, false};
+    int pf[32] = {};
+    int npf = 0, m = M;
+    for (int d = 2; d <= m; ++d)
+        while (m % d == 0) {
+            if (npf >= 32) return s;
+            pf[npf++] = d;
+            m /= d;
+        }
+    bool used[32] = {};
+    int left = npf;
+    while (left > 0) {
+        if (s.np >= 4) return s;
+        int r = 1;
+        for (int i = npf - 1; i >= 0; --i) {
+            if (used[i]) continue;
+            if (r == 1) {
+                if (pf[i] > 31) return s;
+                r = pf[i];
+            } else if (r * pf[i] <= 16) {
+                r *= pf[i];
+            } else {
+                continue;
+            }
+            used[i] = true;
+            --left;
+        }
+        s.r[s.np++] = r;
+    }
+    s.ok = s.np >= 1;
+    return s;
+}
+constexpr bool rader_ok(int R) { return R > 32 && rader_split(R - 1).ok; }
+// LDS of one Rader pass in units of one complex element of `esz` bytes: spectrum of the kernel [M], W_M [M], the two
+// permutations (2 M uint16) and x_0 of every R-point DFT of the tile [inst]
+constexpr int rader_lds_elems(int R, int inst, int esz) { return 2 * (R - 1) + (4 * (R - 1) + esz - 1) / esz + inst; }
+
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
           bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false, typename IT_ = T_, bool WSUB_ = false,
-          bool FS1_ = false>
+          bool FS1_ = false, int RADERM_ = 0>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -236,8 +290,17 @@ struct TileCfg {
     static constexpr bool BIGP1 = NP_ > 1 && R1_ > 32;
     static_assert(!(R2_ > 32 || R3_ > 32) && (!BIGP1 || BIGP0), "cooperative passes come first, at most two");
     static constexpr bool BIGP(int i) { return i == 0 ? BIGP0 : i == 1 ? BIGP1 : false; }
-    static constexpr int CS_OFF(int i) { return i == 0 ? 0 : (BIGP0 ? R0_ : 0); }
-    static constexpr int CS_ELEMS = (BIGP0 ? R0_ : 0) + (BIGP1 ? R1_ : 0);
+    // per cooperative pass: the cos/sin table of R entries (bigprime_pass), or the Rader tables (rader_pass)
+    // (RADERM: bit i = cooperative pass i runs as a Rader convolution; chosen by the host -- it pays from R ~ 128 on and
+    //  needs LDS for its tables -- and uploaded tables go with it)
+    static constexpr bool RADER(int i) { return BIGP(i) && ((RADERM_ >> i) & 1) != 0; }
+    static_assert(RADERM_ == 0 || ((!(RADERM_ & 1) || rader_ok(R0_)) && (!(RADERM_ & 2) || rader_ok(R1_))),
+                  "Rader pass: R - 1 must split into register butterflies");
+    static constexpr int CS_SIZE(int i) {
+        return !BIGP(i) ? 0 : RADER(i) ? rader_lds_elems(R(i), TILE_ * NB(i), 2 * (int)sizeof(T_)) : R(i);
+    }
+    static constexpr int CS_OFF(int i) { return i == 0 ? 0 : CS_SIZE(0); }
+    static constexpr int CS_ELEMS = CS_SIZE(0) + CS_SIZE(1);
     static_assert(!BIGP0 || (!FIRST_DIRECT_ && TWMODE_ == TW_LDS), "big-prime pass 0: tile staged in LDS first");
     // DMA: the flat HBM -> LDS copy of the NEXT tile runs asynchronously (global_load_lds) into a staging
     // buffer behind the twiddle table while this tile's passes execute
@@ -639,7 +702,7 @@ MIFFT_DEV void bigprime_pass(cpx<typename C::T>* lds, const cpx<typename C::T>* 
     }
     __syncthreads();
     // item = (transform, butterfly, group of SB consecutive s): a_j and b_j are read once per j for SB output pairs
-    constexpr int SB = 4, GROUPS = (H + 1 + SB - 1) / SB;
+    constexpr int SB = MIFFT_BIGP_SB, GROUPS = (H + 1 + SB - 1) / SB;
     constexpr int ITEMS = C::TILE * NB * GROUPS;
     constexpr int IPT = (ITEMS + C::THREADS - 1) / C::THREADS;
     V lo[IPT][SB], hi[IPT][SB];
@@ -702,6 +765,96 @@ MIFFT_DEV void bigprime_pass(cpx<typename C::T>* lds, const cpx<typename C::T>* 
     __syncthreads();
 }
 
+// One sub-pass of the M-point FFT inside rader_pass.  K: pass of the split; INV: second (inverse) transform.
+//   gather    K = 0 of the forward transform reads the INPUT positions of the R-point DFT through the permutation g^q
+//             (times the Stockham twiddle of the enclosing pass when I > 0); every other sub-pass reads slots 1..M of the
+//             DFT's OUTPUT block
+//   finish    last sub-pass forward:  slot 0 <- x_0 + A[0];  A[n] <- conj(A[n] * B[n])   (B carries the 1 / M)
+//             last sub-pass inverse:  X[g^-q] = x_0 + conj(d[q]) scattered through the second permutation
+template <class C, int I, int K, bool INV>
+MIFFT_DEV void rader_sub(cpx<typename C::T>* lds, const cpx<typename C::T>* ltw, const cpx<typename C::T>* rt, int tid) {
+    using T = typename C::T;
+    using V = cpx<T>;
+    constexpr int R = C::R(I), M = R - 1, NB = C::NB(I), P = C::P(I), INST = C::TILE * NB;
+    constexpr RaderSplitT S = rader_split(M);
+    constexpr int RK = S.r[K], NBK = M / RK;
+    constexpr int PK = (K == 0 ? 1 : S.r[0]) * (K <= 1 ? 1 : S.r[1]) * (K <= 2 ? 1 : S.r[2]);  // product of the earlier radices
+    constexpr int RATIO = M / (PK * RK);
+    constexpr int ITEMS = INST * NBK, IPT = (ITEMS + C::THREADS - 1) / C::THREADS;
+    constexpr bool LAST = K == S.np - 1;
+    const V* Bt = rt;
+    const V* Wm = rt + M;
+    const unsigned short* perm_in = (const unsigned short*)(rt + 2 * M);
+    const unsigned short* perm_out = perm_in + M;
+    V* x0buf = (V*)rt + 2 * M + (4 * M + (int)sizeof(V) - 1) / (int)sizeof(V);
+    V v[IPT][RK];
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+        const int id = tid + it * C::THREADS;
+        if (ITEMS % C::THREADS == 0 || id < ITEMS) {
+            const int inst = id / NBK, kb = id - inst * NBK;
+            const int c = inst / NB, b = inst - c * NB;
+            const int q = b / P, pp = b - q * P, o0 = q * P * R + pp;
+            if constexpr (K == 0 && !INV) {
+#pragma unroll
+                for (int t = 0; t < RK; ++t) {
+                    const int j = perm_in[kb + t * NBK];  // 1 .. R-1
+                    V u = lds[lds_index<C, I - 1>(c, b + j * NB)];
+                    if constexpr (I > 0) u = cmul(u, ltw[C::TWL_OFF(I) + (j - 1) * P + pp]);
+                    v[it][t] = u;
+                }
+                if (kb == 0) x0buf[inst] = lds[lds_index<C, I - 1>(c, b)];  // (x0buf is outside the data tile)
+            } else {
+                const int ppk = kb % PK;
+#pragma unroll
+                for (int t = 0; t < RK; ++t) {
+                    V u = lds[lds_index<C, I>(c, o0 + (1 + kb + t * NBK) * P)];
+                    if (t > 0 && PK > 1) u = cmul(u, Wm[t * ppk * RATIO]);
+                    v[it][t] = u;
+                }
+            }
+        }
+    }
+    __syncthreads();  // every read of this sub-pass precedes every write (the blocks of different DFTs interleave)
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+        const int id = tid + it * C::THREADS;
+        if (ITEMS % C::THREADS == 0 || id < ITEMS) {
+            const int inst = id / NBK, kb = id - inst * NBK;
+            const int c = inst / NB, b = inst - c * NB;
+            const int q = b / P, pp = b - q * P, o0 = q * P * R + pp;
+            Dft<RK, T, 1>::run(v[it]);
+            const int qk = kb / PK, ppk = kb - qk * PK, n0 = qk * PK * RK + ppk;  // outputs n0 + s * PK
+#pragma unroll
+            for (int s2 = 0; s2 < RK; ++s2) {
+                const int n = n0 + s2 * PK;
+                V y = v[it][s2];
+                if constexpr (LAST && !INV) {
+                    if (n == 0) lds[lds_index<C, I>(c, o0)] = x0buf[inst] + y;  // X_0 = x_0 + sum of the others
+                    y = cmul(y, Bt[n]);
+                    y.y = -y.y;
+                    lds[lds_index<C, I>(c, o0 + (1 + n) * P)] = y;
+                } else if constexpr (LAST && INV) {
+                    y.y = -y.y;
+                    lds[lds_index<C, I>(c, o0 + (int)perm_out[n] * P)] = x0buf[inst] + y;
+                } else {
+                    lds[lds_index<C, I>(c, o0 + (1 + n) * P)] = y;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (!LAST) rader_sub<C, I, K + 1, INV>(lds, ltw, rt, tid);
+}
+
+// A prime radix R > 32 with a smooth R - 1 (C::RADER(I)): Rader's algorithm inside the LDS tile; replaces bigprime_pass.
+// Inputs at positions b + j NB of the staged / previous layout, outputs at the Stockham positions q P R + p + s P.
+template <class C, int I>
+MIFFT_DEV void rader_pass(cpx<typename C::T>* lds, const cpx<typename C::T>* ltw, const cpx<typename C::T>* rt, int tid) {
+    rader_sub<C, I, 0, false>(lds, ltw, rt, tid);  // A = FFT_M(x[g^q]);  slot 0 <- X_0;  slots 1.. <- conj(A B)
+    rader_sub<C, I, 0, true>(lds, ltw, rt, tid);   // d = FFT_M(.);  X[g^-q] = x_0 + conj(d[q])
+}
+
 // 1: the next tile's HBM loads are issued in slices between the passes of the current tile; 0: all at the top
 #ifndef MIFFT_SLICED_PREFETCH
 #define MIFFT_SLICED_PREFETCH 1
@@ -740,7 +893,10 @@ template <class C, int I, int TWSHIFT = 0, class Hook = NoHook, class Hook0 = No
 MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<typename C::T>* twr,
                         cpx<typename C::T> (*pre)[C::R(0)], long long base, int nv, int tid, long long obase = 0,
                         int fs_row = 0, Hook before_stores = Hook(), Hook0 between = Hook0()) {
-    if constexpr (I < C::NP && C::BIGP(I)) {
+    if constexpr (I < C::NP && C::RADER(I)) {
+        rader_pass<C, I>(lds, lds + C::DATA_ELEMS + TWSHIFT, lds + C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(I), tid);
+        run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid, obase, fs_row, before_stores, between);
+    } else if constexpr (I < C::NP && C::BIGP(I)) {
         bigprime_pass<C, I>(lds, lds + C::DATA_ELEMS + TWSHIFT, lds + C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(I), tid);
         run_pass<C, I + 1, TWSHIFT>(p, lds, twr, pre, base, nv, tid, obase, fs_row, before_stores, between);
     } else if constexpr (I < C::NP) {
@@ -811,18 +967,35 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
     if constexpr (C::TWMODE == TW_REG) preload_tw<C, 1>(twr, (const V*)p.tw, tid0, p.inverse);
     if constexpr (C::TWMODE == TW_LDS) {
         fill_lds_tw<C, 1>(lds + C::DATA_ELEMS, (const V*)p.tw, tid0, p.inverse);
-        if constexpr (C::BIGP0) {  // (cos, sin)(2 pi m / R0) from W_N^(m N/R0) = cos - i sin
+        // cooperative passes: (cos, sin)(2 pi m / R) from W_N^(m N/R) = cos - i sin; Rader passes: the plan's tables
+        // (p.tlo: spectrum of the kernel and W_M per Rader pass, complex; p.thi: the two permutations per Rader pass, uint16)
+        if constexpr (C::BIGP0 && !C::RADER(0)) {
             for (int m = tid0; m < C::R(0); m += C::THREADS) {
                 V w = ((const V*)p.tw)[m * C::NB(0)];
                 if (p.inverse) w.y = -w.y;
                 lds[C::DATA_ELEMS + C::TWL_TOTAL + m] = {w.x, -w.y};
             }
         }
-        if constexpr (C::BIGP1) {
+        if constexpr (C::BIGP1 && !C::RADER(1)) {
             for (int m = tid0; m < C::R(1); m += C::THREADS) {
                 V w = ((const V*)p.tw)[m * C::NB(1)];
                 if (p.inverse) w.y = -w.y;
                 lds[C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(1) + m] = {w.x, -w.y};
+            }
+        }
+        if constexpr (C::RADER(0) || C::RADER(1)) {
+            int coff = 0, poff = 0;  // element offsets of this pass's tables in p.tlo / p.thi
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (C::RADER(i)) {
+                    const int M = C::R(i) - 1;
+                    V* dst = lds + C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(i);
+                    for (int m = tid0; m < 2 * M; m += C::THREADS) dst[m] = ((const V*)p.tlo)[coff + m];
+                    unsigned short* pd = (unsigned short*)(dst + 2 * M);
+                    for (int m = tid0; m < 2 * M; m += C::THREADS) pd[m] = ((const unsigned short*)p.thi)[poff + m];
+                    coff += 2 * M;
+                    poff += 2 * M;
+                }
             }
         }
         __syncthreads();

