@@ -14,7 +14,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_LEVEL_WAVES"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pass$i -- python3 $root/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-strong-leg --no-compare-vendor --no-live-pmc > $out/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/pass$i.log; exit 1; }
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pass$i -- python3 $root/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-strong-leg --no-compare-vendor --no-live-pmc --no-copy-ceiling > $out/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/pass$i.log; exit 1; }
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
