@@ -107,21 +107,21 @@ struct Plan {
 // accepts the (plan, pass) pair.
 bool select_generic(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_fast(const Plan& plan, DimPass& pass);
-// wave-autonomous rows of N = 3 * R0 points: radix R0 in registers, radix 3 across three lanes by DPP (kernels_dpp.hip)
+// LAB BUILD ONLY (-DMIFFT_EXPERIMENTAL): wave-autonomous rows of N = 3 * R0 points: radix R0 in registers, radix 3 across
+// three lanes by DPP (kernels_dpp.hip)
 bool select_dpp_rows(const Plan& plan, DimPass& pass);
 // the tile kernel specialised at plan time with hipRTC for a length without a table entry (kernels_jit.cpp)
 bool select_jit(const Plan& plan, DimPass& pass, std::string& why_not);
 // four-step helpers: the transposed + twiddled column pass (reads x: real / integer input allowed) and cheap
 // feasibility predicates for scoring factorisations without compiling
-bool select_jit_streaming_rows(const Plan& plan, DimPass& pass, std::string& why_not);
-// the non-temporal-store window of batched 1-D transforms (bytes moved per exec, kernels_fast.hip);
-// MIFFT_NTS_MIN_BYTES / MIFFT_NTS_MAX_BYTES are tuning knobs
+bool select_jit_streaming_rows(const Plan& plan, DimPass& pass, std::string& why_not);  // LAB BUILD ONLY
+// the non-temporal-store window of batched 1-D transforms (bytes moved per exec, kernels_fast.hip; Config::nts_*)
 bool nts_window(const Plan& plan, double total_bytes);
 // contiguous dimension of N1 * N2 points as a four-step inside one LDS plane (kernels_fast.hip)
 bool select_row2d(const Plan& plan, DimPass& pass);
 bool nts_window_bytes(double total_bytes);  // the same window without the one-dimension condition (single-pass planes)
 bool select_jit_plane(const Plan& plan, DimPass& pass, std::string& why_not);
-// the two innermost dimensions of images that fit one XCD's L2: rows, XCD-local barrier, columns from L2
+// LAB BUILD ONLY: the two innermost dimensions of images that fit one XCD's L2: rows, XCD-local barrier, columns from L2
 bool select_jit_image(const Plan& plan, DimPass& pass, std::string& why_not);
 bool select_jit_tstore(const Plan& plan, DimPass& pass, std::string& why_not);
 // first four-step pass of a strided dimension (TileCfg::FS1): pass.N = N1, pass.fs_n2 = N2

@@ -325,6 +325,12 @@ int main(int argc, char** argv) {
         VN("31x3 t42 126 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 42, 126, false, true, false, TW_LDS, 3, false),
         VN("31x3 t64 192 w3 nt2 fd reg", 2, float, 93, 2, 31, 3, 1, 1, 64, 192, false, true, false, TW_REG, 3, false),
         VN("31x3 t85 255 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 85, 255, false, true, false, TW_LDS, 3, false),
+        // line-aligned tiles (16 rows = 93 lines of 128 B) that leave room for a fourth workgroup per CU
+        VN("31x3 t48 144 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 48, 144, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t48 192 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 48, 192, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t32 128 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 32, 128, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t80 256 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 80, 256, false, true, false, TW_LDS, 3, false),
+        VN("31x3 t64 256 w3 nt2 fd", 2, float, 93, 2, 31, 3, 1, 1, 64, 256, false, true, false, TW_LDS, 3, false),
     };
 #elif GROUP == 3  // ---- 500k x 128 rows (config 1 shape, config 5 z axis; TUNE_BATCH=<rows>) ----
     const long long batch = getenv("TUNE_BATCH") ? atoll(getenv("TUNE_BATCH")) : 500000, outer = 1, inner = 1;
