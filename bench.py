@@ -639,7 +639,7 @@ class Bench:
         peer_counts = [c for r, c in enumerate(counts) if r != 0]
         t_link = (max(peer_counts) * vol_bytes / (link_gbs * 1e9) * 1e3) if peer_counts else 0.0   # ms, one direction
         t_comp = ms_res  # max-over-ranks compute of the resident shards, measured above
-        model = {
+        model = None if not peer_counts else {
             "link_GBs_assumed": link_gbs, "bytes_per_volume": vol_bytes,
             "scatter_ms": round(t_link, 4), "gather_ms": round(t_link, 4), "compute_ms": round(t_comp, 4),
             "serial_ms": round(2 * t_link + t_comp, 4),

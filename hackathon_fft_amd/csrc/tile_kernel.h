@@ -38,9 +38,11 @@
 #define MIFFT_BIGP_SB 4
 #endif
 
-// odd prime radices from this size on use the emit-as-you-go butterfly in LDS-bound passes (pass_compute_scatter)
+// odd prime radices from this size on use the emit-as-you-go butterfly in LDS-bound passes (pass_compute_scatter): radix 31
+// drops from 165 to 145 VGPRs (1023 = 31 * 11 * 3: 0.069 -> 0.055 ms per 128 MB, rows93 real input stops spilling); radices
+// 17 / 19 keep all their outputs in registers anyway and measured 0-7 % slower with it (867 = 17 * 17 * 3)
 #ifndef MIFFT_EMIT_PRIME_MIN
-#define MIFFT_EMIT_PRIME_MIN 17
+#define MIFFT_EMIT_PRIME_MIN 23
 #endif
 
 namespace mifft {

@@ -1,4 +1,5 @@
-"""Cooperative prime pass (radix 37 ... 4093 in LDS): time per 256 MB for a set of lengths, once per value of a kernel-header
+"""Runtime-specialised row kernels (default: lengths with a prime radix 37 ... 4093): time per 128 MB for a set of lengths
+(PROBE_LENGTHS=a,b,c overrides the list), once per value of a kernel-header
 macro (lab build: MIFFT_JIT_DEFINES, one process per value so that the runtime-compiled kernels differ).
     python tools/big_prime_probe2.py [-DMIFFT_BIGP_SB=4 -DMIFFT_BIGP_SB=8 ...]"""
 import os, subprocess, sys
@@ -16,7 +17,9 @@ def factors(n):
         d += 1
     return f
 row = []
-for n in (37, 61, 83, 97, 101, 113, 127, 131, 194, 262, 251, 509, 521, 1009, 2018, 1517, 4093):
+lengths = [int(v) for v in os.environ.get("PROBE_LENGTHS", "").split(",") if v] or \
+    [37, 61, 83, 97, 101, 113, 127, 131, 194, 262, 251, 509, 521, 1009, 2018, 1517, 4093]
+for n in lengths:
     batch = max(1, int(128e6 / (n * 8)))
     x = torch.randn((batch, n, 2), device="cuda:0"); out = torch.empty_like(x)
     with mf.DeviceContext(0) as ctx:
