@@ -85,7 +85,7 @@ OTHER_BASELINE_CONFIGS = ["1d_500kx128", "1d_500kx93_radix31x3", "2d_100x640x480
 # fft/bench.mojo:57-97, shape list :108-124): real in, full complex spectrum out (`rfft_reference_bench` of the N=1 line)
 RFFT_REFERENCE_SHAPES = [(250000, 93), (250000, 128), (100000, 1024), (100, 640, 480), (100, 64, 64, 64),
                          (10, 128, 128, 128), (1, 256, 256, 256)]
-RAMP_S = 0.05
+RAMP_S = float(os.environ.get("MIFFT_BENCH_RAMP_S", "0.05"))  # (the env override is for tools/ramp_probe.sh only)
 
 
 def flops_5nlogn(shape):

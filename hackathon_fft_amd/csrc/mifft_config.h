@@ -49,6 +49,10 @@ struct Config {
     // a length with TWO such primes (1517 = 41 * 37: 0.151 -> 0.186) keeps the cooperative pass below rader_min_pair.
     int rader_min = 33;
     int rader_min_pair = 128;
+    // primes whose R - 1 has a prime factor above 31 (83, 509, 2039 ...): zero-padded convolution of a smooth length >=
+    // 2 R - 3 in a scratch block, from this size on (per 128 MB, cooperative -> padded: 179 0.235 -> 0.229, 263 0.33 -> 0.25,
+    // 509 0.57 -> 0.26, 1019 1.11 -> 0.32, 2039 2.16 -> 0.48; below, the cooperative pass wins: 83 0.142 against 0.295)
+    int rader_pad_min = 200;
 
     // ---- Infinity-Cache policy of N-D schedules: bit 0 non-temporal first pass, bit 1 alternating walk ----
     int nd_mode = 3;
@@ -92,6 +96,7 @@ inline Config load_config() {
     if (const char* v = env("MIFFT_GRID_PER_CU")) c.grid_per_cu = atoi(v);
     if (const char* v = env("MIFFT_JIT_DEFINES")) c.jit_defines = v;
     if (const char* v = env("MIFFT_RADER_MIN")) c.rader_min = c.rader_min_pair = atoi(v);
+    if (const char* v = env("MIFFT_RADER_PAD_MIN")) c.rader_pad_min = atoi(v);
 #endif
 #ifdef MIFFT_TESTING
     if (const char* v = env("MIFFT_TEST_FAIL_SCRATCH_ALLOC")) c.test_fail_scratch_alloc = v[0] == '1';

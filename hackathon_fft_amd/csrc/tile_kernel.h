@@ -182,9 +182,30 @@ constexpr RaderSplitT rader_split(int M) {
     return s;
 }
 constexpr bool rader_ok(int R) { return R > 32 && rader_split(R - 1).ok; }
+// R - 1 with a prime factor above 31 (83, 509, 2039 ...): the cyclic convolution of length M = R - 1 is embedded in one of
+// length L >= 2 M - 1 (zero-padded sequence, wrapped kernel) with L a product of factors <= 16; it runs in a scratch block
+// of L elements per DFT beside the data tile.  0 = none below 8192.
+constexpr bool rader_small_radices(int L) {
+    const RaderSplitT s = rader_split(L);
+    if (!s.ok) return false;
+    for (int i = 0; i < s.np; ++i)
+        if (s.r[i] > 16) return false;
+    return true;
+}
+constexpr int rader_pad_len(int R) {
+    for (int L = 2 * (R - 1) - 1; L <= 8192; ++L)
+        if (rader_small_radices(L)) return L;
+    return 0;
+}
+// convolution length of a Rader pass: M in place, or the padded L
+constexpr int rader_len(int R) { return rader_ok(R) ? R - 1 : rader_pad_len(R); }
 // LDS of one Rader pass in units of one complex element of `esz` bytes: spectrum of the kernel [M], W_M [M], the two
 // permutations (2 M uint16) and x_0 of every R-point DFT of the tile [inst]
-constexpr int rader_lds_elems(int R, int inst, int esz) { return 2 * (R - 1) + (4 * (R - 1) + esz - 1) / esz + inst; }
+// (+ the scratch blocks of a padded pass: inst * L)
+constexpr int rader_lds_elems(int R, int inst, int esz) {
+    const int L = rader_len(R);
+    return 2 * L + (4 * (R - 1) + esz - 1) / esz + inst + (rader_ok(R) ? 0 : inst * L);
+}
 
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
@@ -296,13 +317,15 @@ struct TileCfg {
     // (RADERM: bit i = cooperative pass i runs as a Rader convolution; chosen by the host -- it pays from R ~ 128 on and
     //  needs LDS for its tables -- and uploaded tables go with it)
     static constexpr bool RADER(int i) { return BIGP(i) && ((RADERM_ >> i) & 1) != 0; }
-    static_assert(RADERM_ == 0 || ((!(RADERM_ & 1) || rader_ok(R0_)) && (!(RADERM_ & 2) || rader_ok(R1_))),
-                  "Rader pass: R - 1 must split into register butterflies");
-    static constexpr int CS_SIZE(int i) {
+    static_assert(RADERM_ == 0 || ((!(RADERM_ & 1) || rader_len(R0_) > 0) && (!(RADERM_ & 2) || rader_len(R1_) > 0)),
+                  "Rader pass: no convolution length that splits into register butterflies");
+    static constexpr int cs_size(int i) {
         return !BIGP(i) ? 0 : RADER(i) ? rader_lds_elems(R(i), TILE_ * NB(i), 2 * (int)sizeof(T_)) : R(i);
     }
-    static constexpr int CS_OFF(int i) { return i == 0 ? 0 : CS_SIZE(0); }
-    static constexpr int CS_ELEMS = CS_SIZE(0) + CS_SIZE(1);
+    // (data members: evaluated once at compile time -- a runtime call of rader_len factorises thousands of integers)
+    static constexpr int CS_SIZE0 = cs_size(0), CS_SIZE1 = cs_size(1);
+    static constexpr int CS_OFF(int i) { return i == 0 ? 0 : CS_SIZE0; }
+    static constexpr int CS_ELEMS = CS_SIZE0 + CS_SIZE1;
     static_assert(!BIGP0 || (!FIRST_DIRECT_ && TWMODE_ == TW_LDS), "big-prime pass 0: tile staged in LDS first");
     // DMA: the flat HBM -> LDS copy of the NEXT tile runs asynchronously (global_load_lds) into a staging
     // buffer behind the twiddle table while this tile's passes execute
@@ -778,17 +801,24 @@ MIFFT_DEV void rader_sub(cpx<typename C::T>* lds, const cpx<typename C::T>* ltw,
     using T = typename C::T;
     using V = cpx<T>;
     constexpr int R = C::R(I), M = R - 1, NB = C::NB(I), P = C::P(I), INST = C::TILE * NB;
-    constexpr RaderSplitT S = rader_split(M);
-    constexpr int RK = S.r[K], NBK = M / RK;
+    constexpr bool PAD = !rader_ok(R);   // convolution of length L > M in a scratch block of L elements per DFT
+    constexpr int L = rader_len(R);
+    constexpr RaderSplitT S = rader_split(L);
+    constexpr int RK = S.r[K], NBK = L / RK;
     constexpr int PK = (K == 0 ? 1 : S.r[0]) * (K <= 1 ? 1 : S.r[1]) * (K <= 2 ? 1 : S.r[2]);  // product of the earlier radices
-    constexpr int RATIO = M / (PK * RK);
+    constexpr int RATIO = L / (PK * RK);
     constexpr int ITEMS = INST * NBK, IPT = (ITEMS + C::THREADS - 1) / C::THREADS;
     constexpr bool LAST = K == S.np - 1;
     const V* Bt = rt;
-    const V* Wm = rt + M;
-    const unsigned short* perm_in = (const unsigned short*)(rt + 2 * M);
+    const V* Wm = rt + L;
+    const unsigned short* perm_in = (const unsigned short*)(rt + 2 * L);
     const unsigned short* perm_out = perm_in + M;
-    V* x0buf = (V*)rt + 2 * M + (4 * M + (int)sizeof(V) - 1) / (int)sizeof(V);
+    V* x0buf = (V*)rt + 2 * L + (4 * M + (int)sizeof(V) - 1) / (int)sizeof(V);
+    V* scr = x0buf + INST;  // PAD only: [inst][L]
+    // element n of the running convolution of DFT `inst` sits at blk[n * STR]: slot 1 + n of its output block in the data
+    // tile (the Stockham layout is linear in n: rows stride P, column tiles P * CPITCH), or its scratch block
+    constexpr int STR = PAD ? 1 : (C::COLS ? P * C::CPITCH : P);
+    static_assert(PAD || C::COLS || !is_pow2_ce(C::N), "no swizzle on lengths with a prime factor above 32");
     V v[IPT][RK];
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
@@ -800,17 +830,22 @@ MIFFT_DEV void rader_sub(cpx<typename C::T>* lds, const cpx<typename C::T>* ltw,
             if constexpr (K == 0 && !INV) {
 #pragma unroll
                 for (int t = 0; t < RK; ++t) {
-                    const int j = perm_in[kb + t * NBK];  // 1 .. R-1
-                    V u = lds[lds_index<C, I - 1>(c, b + j * NB)];
-                    if constexpr (I > 0) u = cmul(u, ltw[C::TWL_OFF(I) + (j - 1) * P + pp]);
+                    const int qq = kb + t * NBK;
+                    V u = {(T)0, (T)0};
+                    if (!PAD || qq < M) {  // (padded: the sequence x[g^q] is followed by L - M zeros)
+                        const int j = perm_in[qq];  // 1 .. R-1
+                        u = lds[lds_index<C, I - 1>(c, b + j * NB)];
+                        if constexpr (I > 0) u = cmul(u, ltw[C::TWL_OFF(I) + (j - 1) * P + pp]);
+                    }
                     v[it][t] = u;
                 }
                 if (kb == 0) x0buf[inst] = lds[lds_index<C, I - 1>(c, b)];  // (x0buf is outside the data tile)
             } else {
                 const int ppk = kb % PK;
+                const V* blk = PAD ? scr + inst * L : lds + lds_index<C, I>(c, o0 + P);
 #pragma unroll
                 for (int t = 0; t < RK; ++t) {
-                    V u = lds[lds_index<C, I>(c, o0 + (1 + kb + t * NBK) * P)];
+                    V u = blk[(kb + t * NBK) * STR];
                     if (t > 0 && PK > 1) u = cmul(u, Wm[t * ppk * RATIO]);
                     v[it][t] = u;
                 }
@@ -827,6 +862,7 @@ MIFFT_DEV void rader_sub(cpx<typename C::T>* lds, const cpx<typename C::T>* ltw,
             const int q = b / P, pp = b - q * P, o0 = q * P * R + pp;
             Dft<RK, T, 1>::run(v[it]);
             const int qk = kb / PK, ppk = kb - qk * PK, n0 = qk * PK * RK + ppk;  // outputs n0 + s * PK
+            V* blk = PAD ? scr + inst * L : lds + lds_index<C, I>(c, o0 + P);
 #pragma unroll
             for (int s2 = 0; s2 < RK; ++s2) {
                 const int n = n0 + s2 * PK;
@@ -835,12 +871,12 @@ MIFFT_DEV void rader_sub(cpx<typename C::T>* lds, const cpx<typename C::T>* ltw,
                     if (n == 0) lds[lds_index<C, I>(c, o0)] = x0buf[inst] + y;  // X_0 = x_0 + sum of the others
                     y = cmul(y, Bt[n]);
                     y.y = -y.y;
-                    lds[lds_index<C, I>(c, o0 + (1 + n) * P)] = y;
+                    blk[n * STR] = y;
                 } else if constexpr (LAST && INV) {
                     y.y = -y.y;
-                    lds[lds_index<C, I>(c, o0 + (int)perm_out[n] * P)] = x0buf[inst] + y;
+                    if (!PAD || n < M) lds[lds_index<C, I>(c, o0 + (int)perm_out[n] * P)] = x0buf[inst] + y;
                 } else {
-                    lds[lds_index<C, I>(c, o0 + (1 + n) * P)] = y;
+                    blk[n * STR] = y;
                 }
             }
         }
@@ -849,7 +885,8 @@ MIFFT_DEV void rader_sub(cpx<typename C::T>* lds, const cpx<typename C::T>* ltw,
     if constexpr (!LAST) rader_sub<C, I, K + 1, INV>(lds, ltw, rt, tid);
 }
 
-// A prime radix R > 32 with a smooth R - 1 (C::RADER(I)): Rader's algorithm inside the LDS tile; replaces bigprime_pass.
+// A prime radix R > 32 (C::RADER(I)): Rader's algorithm inside the LDS tile; replaces bigprime_pass.  In place in the DFT's
+// output block when R - 1 splits into register butterflies, through a zero-padded convolution in a scratch block otherwise.
 // Inputs at positions b + j NB of the staged / previous layout, outputs at the Stockham positions q P R + p + s P.
 template <class C, int I>
 MIFFT_DEV void rader_pass(cpx<typename C::T>* lds, const cpx<typename C::T>* ltw, const cpx<typename C::T>* rt, int tid) {
@@ -986,18 +1023,21 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             }
         }
         if constexpr (C::RADER(0) || C::RADER(1)) {
-            int coff = 0, poff = 0;  // element offsets of this pass's tables in p.tlo / p.thi
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (C::RADER(i)) {
-                    const int M = C::R(i) - 1;
-                    V* dst = lds + C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(i);
-                    for (int m = tid0; m < 2 * M; m += C::THREADS) dst[m] = ((const V*)p.tlo)[coff + m];
-                    unsigned short* pd = (unsigned short*)(dst + 2 * M);
-                    for (int m = tid0; m < 2 * M; m += C::THREADS) pd[m] = ((const unsigned short*)p.thi)[poff + m];
-                    coff += 2 * M;
-                    poff += 2 * M;
-                }
+            // per Rader pass: complex [B (L) | W_L (L)] from p.tlo, uint16 [g^q (M) | g^-q (M)] from p.thi.  Everything here
+            // is a compile-time constant (a runtime call of rader_len would factorise thousands of integers per thread)
+            constexpr int L0 = C::RADER(0) ? rader_len(C::R(0)) : 0, M0 = C::RADER(0) ? C::R(0) - 1 : 0;
+            constexpr int L1 = C::RADER(1) ? rader_len(C::R(1)) : 0, M1 = C::RADER(1) ? C::R(1) - 1 : 0;
+            if constexpr (C::RADER(0)) {
+                V* dst = lds + C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(0);
+                for (int m = tid0; m < 2 * L0; m += C::THREADS) dst[m] = ((const V*)p.tlo)[m];
+                unsigned short* pd = (unsigned short*)(dst + 2 * L0);
+                for (int m = tid0; m < 2 * M0; m += C::THREADS) pd[m] = ((const unsigned short*)p.thi)[m];
+            }
+            if constexpr (C::RADER(1)) {
+                V* dst = lds + C::DATA_ELEMS + C::TWL_TOTAL + C::CS_OFF(1);
+                for (int m = tid0; m < 2 * L1; m += C::THREADS) dst[m] = ((const V*)p.tlo)[2 * L0 + m];
+                unsigned short* pd = (unsigned short*)(dst + 2 * L1);
+                for (int m = tid0; m < 2 * M1; m += C::THREADS) pd[m] = ((const unsigned short*)p.thi)[2 * M0 + m];
             }
         }
         __syncthreads();

@@ -179,15 +179,18 @@ def test_rows_with_a_large_prime_factor(n):
 
 
 @pytest.mark.parametrize("n,rader", [(97, True), (37, True), (194, True), (1009, True), (4093, True), (2 * 251, True),
-                                     (83, False),         # 82 = 2 * 41: no register butterfly for 41
-                                     (509, False),        # 508 = 4 * 127
+                                     (83, False),         # 82 = 2 * 41: no in-place split, below the padded threshold
+                                     (509, True),         # 508 = 4 * 127: zero-padded convolution of length 1024
+                                     (2039, True), (263, True), (3 * 337, True),   # ... 4096; 262 = 2 * 131 -> 528; 336: in place
+                                     (167, False),        # 166 = 2 * 83, below the padded threshold of 200
                                      (37 * 41, False),    # two such primes below 128: both cooperative
                                      (131 * 37, True)])   # ... 131 by Rader, 37 cooperative
 def test_which_prime_passes_run_as_rader_convolutions(n, rader):
     """Prime radices above 32: x[g^q] (*) W_R^(g^-q) through an (R - 1)-point FFT, a pointwise product with the
     precomputed spectrum and an inverse FFT, all inside the LDS tile (tile_kernel.h rader_pass) -- 2x faster at R = 97,
-    6x at 1009, 14x at 4093 than the O(R^2 / 4) cooperative pass, which remains for primes whose R - 1 has a prime factor
-    above 31.  Parity against fp64 pocketfft, forward and inverse, complex, real and fp64."""
+    6x at 1009, 14x at 4093 than the O(R^2 / 4) cooperative pass.  Primes whose R - 1 has a prime factor above 31 embed the
+    convolution in a zero-padded one of smooth length (scratch block in LDS) from R = 200 on; below that the cooperative
+    pass remains.  Parity against fp64 pocketfft, forward and inverse, complex, real and fp64."""
     rng = np.random.default_rng(n)
     f, m, d = [], n, 2
     while m > 1:
@@ -200,7 +203,7 @@ def test_which_prime_passes_run_as_rader_convolutions(n, rader):
         x = rng.standard_normal((7, n, comps)).astype(dtype)
         out, plan = _run(x, bases=[f])
         # (fp64 at 4093 points: the tables -- 2 x 4092 complex doubles -- no longer fit LDS beside the row: cooperative)
-        want = rader and not (n == 4093 and dtype == np.float64)
+        want = rader and not (n in (4093, 2039) and dtype == np.float64)
         assert ("_rader" in plan.kernel_name(0)) == want, plan.kernel_name(0)
         z = x[..., 0].astype(np.float64) + (1j * x[..., 1] if comps == 2 else 0)
         assert rel_l2(out, from_complex(np.fft.fft(z, axis=1), np.float64)) < tol, plan.kernel_name(0)
