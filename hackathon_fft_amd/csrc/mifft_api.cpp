@@ -117,6 +117,9 @@ static int device_count_quiet() {
 
 using namespace mifft;
 
+// The library is built with -fvisibility=hidden: ONLY the C ABI below is exported.  (Its internal C++ names live in namespace
+// mifft; exported, they would interpose with equally named symbols of the program that loads the library.)
+#pragma GCC visibility push(default)
 extern "C" {
 
 const char* mifft_last_error(void) { return g_last_error.c_str(); }
@@ -573,3 +576,4 @@ int mifft_jit_precompile(int in_dtype, int out_dtype, int64_t length, int stride
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

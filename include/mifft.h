@@ -204,7 +204,7 @@ size_t mifft_plan_scratch_bytes(const mifft_plan* plan);
 
 /*
  * mifft_plan_device_status -- device-side error flags of the execs enqueued so far with this plan on `stream`;
- * reads and clears them.  Only the opt-in L2-resident image kernel (MIFFT_JIT_IMAGE=1) can raise one: its
+ * reads and clears them.  Only the experimental L2-resident image kernel of the LAB build can raise one: its
  * XCD-local barrier spins are bounded, and an exec whose spin expired (bit 0) or that was dispatched with a surplus
  * workgroup on one XCD (bit 1) has produced output that must not be trusted.  Every other kernel family has no
  * inter-workgroup dependency and reports 0 without touching the device.  SYNCHRONISES `stream` when the plan
