@@ -153,3 +153,33 @@ def test_slab_plan_rejects_a_whole_batch_smaller_than_the_slab():
     rc = L.mifft_plan_create_slab(ctypes.byref(h), 0, 0, 0, 1, dims, 8, 2, 0, None, None, 0, 4)
     assert rc == -9 or rc < 0 and "whole_batch" in L.mifft_last_error().decode()
     assert not h.value
+
+
+def test_only_the_c_abi_is_exported_and_the_product_library_has_no_lab_switches():
+    """libmifft.so is built with -fvisibility=hidden: the dynamic symbol table holds the entry points of include/mifft.h
+    and no internal C++ function (an exported `mifft::Plan::~Plan` once interposed with a host program's class of the same
+    name).  The measurement switches and the fault injection exist in libmifft_lab.so only."""
+    import re
+    import shutil
+    import subprocess
+    from hackathon_fft_amd._lib import EXPORTS
+    nm = shutil.which("nm")
+    if nm is None:
+        pytest.skip("no nm")
+    libdir = os.path.join(ROOT, "hackathon_fft_amd", "csrc")
+    out = subprocess.run([nm, "-D", "--defined-only", os.path.join(libdir, "libmifft.so")], capture_output=True, text=True,
+                         check=True).stdout
+    funcs = [ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "Tt"]
+    assert sorted(funcs) == sorted(EXPORTS), sorted(set(funcs) ^ set(EXPORTS))
+    blob = open(os.path.join(libdir, "libmifft.so"), "rb").read()
+    lab_switches = ["MIFFT_ND_CACHE", "MIFFT_NTS_MIN_BYTES", "MIFFT_FOURSTEP_STRIDED", "MIFFT_FOURSTEP_MIN_N", "MIFFT_DPP",
+                    "MIFFT_TEST_FAIL_SCRATCH_ALLOC", "MIFFT_RADER_MIN", "MIFFT_GRID_PER_CU", "MIFFT_JIT_IMAGE", "MIFFT_ROW2D",
+                    "MIFFT_JIT_NT", "MIFFT_JIT_DEFINES", "MIFFT_FS_N1"]
+    # (as C strings: the kernel headers embedded for the runtime compiler mention macro names, never NUL-terminated)
+    assert [n for n in lab_switches if n.encode() + b"\0" in blob] == []
+    for n in ("MIFFT_JIT", "MIFFT_JIT_CACHE_DIR", "MIFFT_JIT_VERBOSE"):
+        assert n.encode() + b"\0" in blob, n
+    lab = os.path.join(libdir, "libmifft_lab.so")
+    if os.path.exists(lab):
+        lab_blob = open(lab, "rb").read()
+        assert [n for n in lab_switches if n.encode() + b"\0" not in lab_blob] == []
