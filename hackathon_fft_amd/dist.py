@@ -70,8 +70,8 @@ class ShardedFFT:
     (results then agree with the single-GPU plan to rounding, not bit for bit); bench.py's strong-scaling leg times both.
     (The CPU test-suite injects the oracle as ``local_backend`` to exercise the sharding and the P2P plumbing over gloo.)
 
-    Construction is COLLECTIVE when a process group is initialised (it creates the second group the root-held pipeline
-    returns its results on): every rank of ``group`` must construct its ShardedFFT at the same point.
+    ``fft_from_root`` is a COLLECTIVE call: every rank of ``group`` calls it at the same point (the first call also
+    creates the second process group the pipeline returns its results on).
     """
 
     def __init__(self, in_dtype, out_dtype, in_shape: Sequence[int], out_shape: Sequence[int], *, bases=None,
@@ -81,11 +81,9 @@ class ShardedFFT:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # results return on their own group = their own communicator (and, under RCCL, their own stream): the gather of
-        # chunk k overlaps the scatter of chunk k + 1
+        # chunk k overlaps the scatter of chunk k + 1.  Created by the first fft_from_root (a collective call anyway), so
+        # that resident-shard use never creates a second communicator.
         self.group_back = None
-        if dist.is_initialized() and self.world > 1:
-            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-            self.group_back = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
         self.max_chunks = 8  # chunks per slab in fft_from_root (one chunk >= one batch entry)
         self.in_shape, self.out_shape = tuple(in_shape), tuple(out_shape)
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
@@ -179,6 +177,9 @@ class ShardedFFT:
             self.fft(out_slab, x_slab)
             out_full.copy_(out_slab)
             return
+        if self.group_back is None and self.world > 1:
+            ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(dist.get_world_size()))
+            self.group_back = dist.new_group(ranks=ranks, backend=dist.get_backend(self.group))
         back = self.group_back if self.group_back is not None else self.group
         gloo = dist.get_backend(self.group) == "gloo"
         if not is_root or loopback:

@@ -290,6 +290,11 @@ int main(int argc, char** argv) {
     const int N = 1024;
     std::vector<Variant> vs = {
         VN("4x4x8x8 t4 512 lds w2 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, false),
+        // the same kernel forced under 80 / 64 VGPRs (82 as it stands: two workgroups per CU resident, four launched)
+        VN("4x4x8x8 t4 512 lds w6 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 6, false),
+        VN("4x4x8x8 t4 512 lds w8 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 8, false),
+        VN("4x4x8x8 t2 256 lds w6 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 6, false),
+        VN("4x4x8x8 t2 256 lds w4 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 4, false),
         VN("4x4x8x8 t4 512 lds w2 pf nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 2, true),
         VN("4x4x8x8 t4 512 lds w4 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, true, true, TW_LDS, 4, false),
         VN("4x4x8x8 t2 256 lds w4 nt3", 3, float, 1024, 4, 4, 4, 8, 8, 2, 256, false, true, true, TW_LDS, 4, false),
