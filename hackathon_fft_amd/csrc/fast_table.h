@@ -7,6 +7,9 @@
 
 namespace mifft {
 
+// columns of a Hermitian column space (d1 x d2, d1 = 1 for a 2-D plan) that are not beyond their own mirror: a flat prefix
+inline long long herm_prefix(int d1, int d2) { return d1 > 1 ? (long long)(d1 / 2 + 1) * d2 : d2 / 2 + 1; }
+
 template <class C>
 static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, void* out, int64_t count,
                        hipStream_t stream) {
@@ -24,6 +27,11 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
     if (C::COLS) {
         tp.inner = pass.inner;
         tp.tiles_per_outer = (pass.inner + C::TILE - 1) / C::TILE;
+        if (C::HERM) {  // last pass of a real-input N-D plan: only the columns up to their mirror are transformed
+            tp.herm_d1 = pass.herm_d1;
+            tp.herm_d2 = pass.herm_d2;
+            tp.tiles_per_outer = (herm_prefix(pass.herm_d1, pass.herm_d2) + C::TILE - 1) / C::TILE;
+        }
         tp.n_tiles = count * pass.outer * tp.tiles_per_outer;
     } else {
         tp.n_rows = count * pass.outer;
@@ -70,6 +78,7 @@ struct FastEntry {
     int (*prepare)();
     int tile, threads;
     size_t lds;
+    bool herm = false;  // TileCfg::HERM twin: last (strided, in-place) pass of a real-input 2-D / 3-D plan
 };
 
 #define MIFFT_TILECFG(TS, REAL, NTM, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF) \
@@ -84,6 +93,18 @@ struct FastEntry {
     }
 
 #define MIFFT_CFG(...) MIFFT_CFG_X(false, false, 0, -1, __VA_ARGS__)
+// Hermitian twin of a strided configuration (TileCfg::HERM), optionally with wave-owned sub-problems
+#define MIFFT_CFG_HERM_X(WS, NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                              \
+    {                                                                                                                                      \
+        false, false, -1, DT, N, COLS, NAME "_h",                                                                                          \
+            launch_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, false, false, 0, false, T, WS, false, 0, true>>,  \
+            prepare_tile<TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, false, false, 0, false, T, WS, false, 0, true>>, \
+            TILE, THREADS,                                                                                                                 \
+            TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, false, false, 0, false, T, WS, false, 0, true>::LDS_BYTES,     \
+            true                                                                                                                           \
+    }
+#define MIFFT_CFG_HERM(...) MIFFT_CFG_HERM_X(false, __VA_ARGS__)
+#define MIFFT_CFG_WSUB_HERM(...) MIFFT_CFG_HERM_X(true, __VA_ARGS__)
 // column tile whose passes 1..NP-1 run inside wave-owned sub-problems (TileCfg::WSUB): R0 a multiple of THREADS / 64
 #define MIFFT_CFG_WSUB(NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                        \
     {                                                                                                                          \

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/mifft.h"
+#include "mifft_config.h"
 
 namespace mifft {
 
@@ -72,6 +73,12 @@ struct DimPass {
     void* d_aux3 = nullptr;           // TSTORE passes: [tile][N] table of W^(c*k1) for the columns of one tile
     bool reverse = false;             // in-place pass that walks its tiles last-to-first (TileParams::reverse)
     int wg_per_cu = 0;                // workgroups per CU of the persistent grid (0 = the LDS / wave-count formula)
+    // last pass of a real-input 2-D / 3-D plan: the kernel families may take a Hermitian twin (TileCfg::HERM) that reads
+    // and transforms only the columns up to their mirror.  want_herm is set by the scheduler, herm_d1 / herm_d2 (the
+    // trailing dimensions of the column space) by the family that selected such a kernel (0 = an ordinary kernel).
+    bool want_herm = false;
+    bool herm_only = false;  // (select_fast: accept only Hermitian twins -- the scheduler tries those first)
+    int herm_d1 = 0, herm_d2 = 0;
 };
 
 struct Plan {
@@ -102,6 +109,21 @@ struct Plan {
     size_t in_elem_bytes() const;
     size_t out_elem_bytes() const;  // bytes of one complex output element
 };
+
+// Does a Hermitian twin (TileCfg::HERM) with `tile` columns per tile pay for this pass?  Measured with tools/herm_probe.py
+// (DESIGN_EXPERIMENTS.md R3.6):
+//   * tiles of whole 128-byte lines store their mirrored lines whole (contiguous runs with a carried column): 5-11 % of the
+//     whole transform at every size -- provided the rows of the trailing dimension are a whole number of tiles, or the
+//     tensor stays in the Infinity Cache, where the partial lines merge;
+//   * narrower tiles (strided dimensions beyond ~1024 points) store every mirrored line in pieces: a gain (3-15 %) only
+//     while the tensor is cache resident, and none at all for 4-column tiles.
+inline bool herm_pays(const Plan& plan, const DimPass& pass, int tile) {
+    const double out_bytes = plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes();
+    const bool resident = out_bytes <= (double)kInfinityCacheBytes;
+    const long long d2 = plan.dims[plan.ndim - 1];
+    if ((long long)tile * (long long)plan.out_elem_bytes() >= 128) return d2 % tile == 0 || resident;
+    return resident && pass.N <= 2048;
+}
 
 // kernel families; each returns true and fills pass.launch/tile/... when it
 // accepts the (plan, pass) pair.

@@ -124,6 +124,9 @@ struct TileParams {
     // FS1 configurations: `inner` is the LOAD row stride N2 * fs_inner; rows are stored at stride fs_inner
     long long fs_inner;
     long long fs_n2;
+    // HERM configurations (last pass of a REAL-input N-D plan, in place): the trailing dimensions (d1, d2) of the column
+    // index space (d1 = 1 for a 2-D plan); tiles_per_outer covers only the flat prefix [0, (d1/2 + 1) * d2) of the columns
+    int herm_d1, herm_d2;
 };
 
 MIFFT_DEV long long tile_id(const TileParams& p, long long t) { return p.reverse ? p.n_tiles - 1 - t : t; }
@@ -210,7 +213,7 @@ constexpr int rader_lds_elems(int R, int inst, int esz) {
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
           bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false, typename IT_ = T_, bool WSUB_ = false,
-          bool FS1_ = false, int RADERM_ = 0>
+          bool FS1_ = false, int RADERM_ = 0, bool HERM_ = false>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -300,6 +303,13 @@ struct TileCfg {
     // TILE-element runs and need no LDS round trip.  The second pass (an ordinary column tile of N2 points at row
     // stride N1 * fs_inner) then leaves the spectrum in natural order.
     static constexpr bool FS1 = FS1_;
+    // HERM (column tiles, in place): the LAST pass of a real-input N-D transform.  The spectrum of a real tensor is
+    // Hermitian, Y[-k, -c] = conj(Y[k, c]) over the transformed dimensions, and so is every intermediate over the dimensions
+    // already transformed: column -c of this pass holds the conjugate of column c.  Only the columns c <= -c (a flat prefix
+    // of the column space) are read and transformed; every result is stored twice, at (k, c) and conjugated at (-k, -c).
+    // Half the reads and butterflies of the pass; the reference computes (and this library's other kernels compute) all of it.
+    static constexpr bool HERM = HERM_;
+    static_assert(!HERM_ || (COLS_ && LAST_DIRECT_ && !TSTORE_ && !FS1_), "HERM: a direct in-place column tile");
     static_assert(!FS1_ || (COLS_ && FIRST_DIRECT_ && LAST_DIRECT_ && !TSTORE_ && !WSUB_), "FS1: a direct column tile");
     static constexpr int CPITCH = TSTORE_ ? TILE_ + 1 : TILE_;
     static_assert(!TSTORE_ || (COLS_ && !LAST_DIRECT_ && FIRST_DIRECT_), "TSTORE: column tile, last pass left in LDS");
@@ -332,9 +342,16 @@ struct TileCfg {
     static constexpr bool DMA = DMA_;
     static constexpr int STAGE_OFF = ((DATA_ELEMS + TWL_TOTAL) * 2 * (int)sizeof(T_) + 15) / 16 * 16 / (2 * (int)sizeof(T_));
     static constexpr int STAGE_ELEMS = DMA_ ? N_ * TILE_ : 0;
+    // HERM: one column of N results carried from a tile to the next one of the workgroup's run (see the HERM stores)
+    // (full-line tiles only: narrower ones need the XCD_CHUNK order above -- their neighbours have to run at the same time
+    //  on one XCD, or every line is fetched once per tile that shares it: 4-column tiles 1.5-1.6x slower in runs)
+    static constexpr bool HERM_RUNS = HERM_ && !XCD_CHUNK;
+    static constexpr int HERM_OFF = DATA_ELEMS + TWL_TOTAL + CS_ELEMS;
+    static constexpr int HERM_ELEMS = HERM_RUNS ? N_ : 0;
+    static_assert(!(HERM_ && DMA_), "HERM: no staging buffer");
     static constexpr size_t LDS_BYTES =
         DMA_ ? (size_t)(STAGE_OFF + STAGE_ELEMS) * 2 * sizeof(T_)
-             : (size_t)(DATA_ELEMS + TWL_TOTAL + CS_ELEMS) * 2 * sizeof(T_);
+             : (size_t)(DATA_ELEMS + TWL_TOTAL + CS_ELEMS + HERM_ELEMS) * 2 * sizeof(T_);
     static_assert(P(NP_) == N_, "radices must multiply to N");
     static_assert(LDS_BYTES <= 160 * 1024, "tile + twiddle table exceed the CU's 160 KiB of LDS");
 };
@@ -631,6 +648,12 @@ MIFFT_DEV void pass_gather_lds(const TileParams& p, const cpx<typename C::T>* sr
     }
 }
 
+// HERM: the flat column (ky, kx) of the trailing dimensions (herm_d1 x herm_d2) mirrors to (-ky, -kx)
+MIFFT_DEV int herm_mirror(const TileParams& p, int cf) {
+    const int d2 = p.herm_d2, ky = cf / d2, kx = cf - ky * d2;
+    return (ky ? p.herm_d1 - ky : 0) * d2 + (kx ? d2 - kx : 0);
+}
+
 // registers -> butterflies -> Stockham scatter (LDS, or HBM for the last pass)
 template <class C, int I>
 MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds, cpx<typename C::T> (*v)[C::R(I)],
@@ -674,6 +697,53 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
                         }
                         gstore<(C::NT & 2) != 0>(gout + obase + s * step + off, y);
                     }
+                }
+            } else if constexpr (DST_GLOBAL && C::HERM) {
+                // Every result goes to (k, cf) and, conjugated, to the mirrored point (-k, mf).  The mirror image of an
+                // aligned run of TILE columns [c0, c0 + TILE) is the run [m - TILE + 1, m], which starts ONE element past a
+                // line boundary: stored as it stands, every mirrored line would be written by two tiles in two pieces
+                // (15 + 1 elements for 16-column tiles), each store instruction touching twice the lines -- measured 13-15 %
+                // of the whole transform (DESIGN_EXPERIMENTS.md R3.6).  So a workgroup walks a CONTIGUOUS run of tiles in
+                // DESCENDING column order and the lane of a tile's first column does not store its own mirror image: it
+                // keeps the column in LDS (`carry`, N elements) and stores the column the previous tile kept, which is the
+                // missing first element of this tile's mirrored lines.  Only the ends of a run store single elements.
+                //   obase = the image's base (outer index); fs_row = the tile's first flat column (bits 0..29),
+                //   bit 30: the previous tile of the run left its first column in `carry`, bit 31: leave this tile's there
+                const int col0 = fs_row & 0x3fffffff;
+                const bool carry_in = (fs_row >> 30) & 1, carry_out = ((unsigned)fs_row >> 31) != 0;
+                const int cf = col0 + c, mf = herm_mirror(p, cf);
+                const bool alive = c < nv && cf <= mf;  // (columns beyond their mirror belong to the mirror's tile)
+                const bool first = c == 0, twice = alive && cf < mf;
+                const bool keep = first && twice && carry_out;              // first column: left in LDS for the next tile,
+                const bool lone = first && twice && !carry_out && carry_in;  // or stored by itself at the end of a run
+                const bool mirrored = first ? carry_in || (twice && !carry_out) : twice;           // the mirrored store ...
+                const int mcol = first && carry_in ? herm_mirror(p, col0 + C::TILE) : mf;  // ... and its column
+                V* carry = lds + C::HERM_OFF;
+                const unsigned off = lane_off<C>(p, c, o0);
+                const long long step = (long long)P * elem_stride<C>(p);  // uniform
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    V y = v[k][s];
+                    if (p.inverse) {
+                        y.x *= (T)p.scale;
+                        y.y *= -(T)p.scale;
+                    }
+                    if (alive) gstore<(C::NT & 2) != 0>(gout + base + s * step + off, y);
+                    const int kk = o0 + s * P, kr = kk ? C::N - kk : 0;
+                    V* const mrow = gout + obase + (long long)kr * p.inner;
+                    V z = y;
+                    // (the thread that reads carry[kk] here is the one that wrote it in the previous tile: no barrier)
+                    if constexpr (C::HERM_RUNS) {
+                        if (first && carry_in) z = carry[kk];
+                        if (keep) carry[kk] = y;
+                    }
+                    if (lone) {
+                        V w = y;
+                        w.y = -w.y;
+                        gstore<(C::NT & 2) != 0>(mrow + mf, w);
+                    }
+                    z.y = -z.y;
+                    if (mirrored) gstore<(C::NT & 2) != 0>(mrow + mcol, z);
                 }
             } else if constexpr (DST_GLOBAL) {
                 if (c < nv) {
@@ -1047,6 +1117,16 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
     V pre[C::PREFETCH ? C::IPT(0) : 1][C::R(0)];
     // this workgroup's tiles: t, t + t_step, ... < t_end
     long long t = blockIdx.x, t_end = p.n_tiles, t_step = gridDim.x;
+    long long run_begin = 0;
+    if constexpr (C::HERM_RUNS) {  // one contiguous run of tiles per workgroup (lengths differ by one at most), walked in
+                                   // descending column order (HERM stores)
+        const long long len = p.n_tiles / gridDim.x, rem = p.n_tiles - len * gridDim.x, w = blockIdx.x;
+        run_begin = t = w * len + (w < rem ? w : rem);
+        t_end = t + len + (w < rem ? 1 : 0);
+        t_step = 1;
+    }
+    // (runs: position t of the order is tile n_tiles - 1 - t, whatever p.reverse says)
+    auto tile_at = [&](long long pos) { return C::HERM_RUNS ? p.n_tiles - 1 - pos : tile_id(p, pos); };
     if constexpr (C::XCD_CHUNK) {
         if (gridDim.x >= 8) {  // (smaller grids: some XCD would own tiles but no workgroup)
             const long long x = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -1060,7 +1140,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
         if (t < t_end) {
             long long base;
             int nv;
-            tile_geom<C>(p, tile_id(p, t), base, nv);
+            tile_geom<C>(p, tile_at(t), base, nv);
             load_pass0<C>(p, pre, base, nv, tid0);
         }
     }
@@ -1076,13 +1156,30 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
 #endif
         long long base;
         int nv;
-        const long long tt = tile_id(p, t);
+        const long long tt = tile_at(t);
         long long obase = 0;
         int fs_row = 0;
-        if constexpr (C::FS1)
+        if constexpr (C::FS1) {
             tile_geom_fs1<C>(p, tt, base, obase, nv, fs_row);
-        else
+        } else {
             tile_geom<C>(p, tt, base, nv);
+            if constexpr (C::HERM) {  // image base and first column of the tile, for the mirrored stores
+                const long long in_image = tt % p.tiles_per_outer;
+                fs_row = (int)(in_image * C::TILE);
+                obase = base - fs_row;
+                // tile tt hands its first column to tile tt - 1 when that is the next of this run, lies in the same image,
+                // and the column has a mirror image at all; the same test one tile up says whether tile tt + 1 did so
+                // (not across the start of a row of the trailing dimension: that column's mirror image is the FIRST element
+                //  of a row, next to nothing the neighbouring tile stores)
+                if constexpr (C::HERM_RUNS) {
+                    const int nxt = fs_row + C::TILE;
+                    const bool out = t + 1 < t_end && fs_row % p.herm_d2 != 0 && fs_row < herm_mirror(p, fs_row);
+                    const bool in = t > run_begin && in_image + 1 != p.tiles_per_outer && nxt % p.herm_d2 != 0 &&
+                                    nxt < herm_mirror(p, nxt);
+                    fs_row |= (in ? 1 << 30 : 0) | (out ? (int)(1u << 31) : 0);
+                }
+            }
+        }
         V cur[C::PREFETCH ? C::IPT(0) : 1][C::R(0)];
         // seams between passes where a slice of the next tile's loads can go: 2 NP - 3 of them, plus the top
         // (column tiles only: row tiles measured 4-8 % SLOWER sliced -- rows480 0.096 -> 0.104 ms, tools/tune GROUP 5 --
@@ -1096,7 +1193,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             for (int k = 0; k < C::IPT(0); ++k)
 #pragma unroll
                 for (int j = 0; j < C::R(0); ++j) cur[k][j] = pre[k][j];
-            if (tn < t_end) tile_geom<C>(p, tile_id(p, tn), nbase, nnv);
+            if (tn < t_end) tile_geom<C>(p, tile_at(tn), nbase, nnv);
             if constexpr (SLICES == 1) {
                 if (tn < t_end) load_pass0<C>(p, pre, nbase, nnv, tid);  // all of the next tile's HBM reads at once
             } else {

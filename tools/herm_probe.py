@@ -1,0 +1,41 @@
+"""Hermitian twins of the last pass of real-input N-D plans (TileCfg::HERM) against the ordinary column kernels, same process,
+lab library (MIFFT_HERM is re-read at every plan creation there).
+    MIFFT_LIBRARY=hackathon_fft_amd/csrc/libmifft_lab.so python tools/herm_probe.py [shape ...]   (shape = 100x640x480)"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import hackathon_fft_amd as mf  # noqa: E402
+
+SHAPES = ["25x640x480", "100x640x480", "200x640x480", "400x640x480", "10x1920x1080", "20x1920x1080", "40x1920x1080",
+          "1x3840x2160", "4x3840x2160", "8x3840x2160", "50x64x64x64", "100x64x64x64", "200x64x64x64", "400x64x64x64",
+          "10x128x128x128", "20x128x128x128", "40x128x128x128", "1x256x256x256", "4x256x256x256", "8x256x256x256",
+          "1x512x512x512", "1000x96x80", "64x1024x1024", "16x2048x2048", "6x360x360x360"]
+
+
+def main():
+    shapes = [a for a in sys.argv[1:] if "x" in a] or SHAPES
+    print(f"{'shape':>18} {'out MB':>8} {'off ms':>8} {'on ms':>8} {'on/off':>7}  kernels (on)")
+    for spec in shapes:
+        shape = tuple(int(v) for v in spec.split("x"))
+        x = torch.randn(shape + (1,), device="cuda:0")
+        out = torch.empty(shape + (2,), device="cuda:0")
+        res = {}
+        for mode in ("0", "1", "0", "1"):
+            os.environ["MIFFT_HERM"] = mode
+            with mf.DeviceContext(0) as ctx:
+                plan = mf.plan_fft(torch.float32, torch.float32, x.shape, out.shape, ctx=ctx)
+                mf.time_fft(out, x, plan=plan, iters=10, ctx=ctx)
+                ms = min(mf.time_fft(out, x, plan=plan, iters=30, ctx=ctx) for _ in range(3))
+                res[mode] = min(ms, res.get(mode, 1e9))
+                name = plan.kernel_name(0)
+            del plan
+        print(f"{spec:>18} {out.numel() * 4 / 1e6:8.0f} {res['0']:8.4f} {res['1']:8.4f} {res['1'] / res['0']:7.3f}  {name}", flush=True)
+        del x, out
+
+
+if __name__ == "__main__":
+    main()
