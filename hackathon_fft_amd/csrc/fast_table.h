@@ -7,9 +7,6 @@
 
 namespace mifft {
 
-// columns of a Hermitian column space (d1 x d2, d1 = 1 for a 2-D plan) that are not beyond their own mirror: a flat prefix
-inline long long herm_prefix(int d1, int d2) { return d1 > 1 ? (long long)(d1 / 2 + 1) * d2 : d2 / 2 + 1; }
-
 template <class C>
 static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, void* out, int64_t count,
                        hipStream_t stream) {
@@ -28,9 +25,10 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
         tp.inner = pass.inner;
         tp.tiles_per_outer = (pass.inner + C::TILE - 1) / C::TILE;
         if (C::HERM) {  // last pass of a real-input N-D plan: only the columns up to their mirror are transformed
+            tp.herm_d0 = pass.herm_d0;
             tp.herm_d1 = pass.herm_d1;
             tp.herm_d2 = pass.herm_d2;
-            tp.tiles_per_outer = (herm_prefix(pass.herm_d1, pass.herm_d2) + C::TILE - 1) / C::TILE;
+            tp.tiles_per_outer = (herm_prefix(pass.herm_d0, pass.herm_d1, pass.herm_d2) + C::TILE - 1) / C::TILE;
         }
         tp.n_tiles = count * pass.outer * tp.tiles_per_outer;
     } else {
@@ -78,7 +76,7 @@ struct FastEntry {
     int (*prepare)();
     int tile, threads;
     size_t lds;
-    bool herm = false;  // TileCfg::HERM twin: last (strided, in-place) pass of a real-input 2-D / 3-D plan
+    bool herm = false;  // TileCfg::HERM twin: last (strided, in-place) pass of a real-input 2-D .. 4-D plan
 };
 
 #define MIFFT_TILECFG(TS, REAL, NTM, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF) \

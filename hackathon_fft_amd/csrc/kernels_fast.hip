@@ -81,7 +81,7 @@ static const FastEntry kFastTable[] = {
     // ten waves, one per sub-problem of the radix-10 first pass (WSUB): the 8 x 8 passes exchange without workgroup
     // barriers, the waves drift apart and overlap each other's HBM traffic; with the next tile's loads issued in slices
     // between the passes 0.1009 -> 0.0969 ms for 100 x 640 x 480 (tools/tune GROUP 20)
-    // Hermitian twins (last pass of a real-input 2-D / 3-D plan; listed first, taken only when the pass asks for one)
+    // Hermitian twins (last pass of a real-input 2-D .. 4-D plan; listed first, taken only when the pass asks for one)
     MIFFT_CFG_WSUB_HERM("cols640_10x8x8_ws", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_LDS, 1, true),
     MIFFT_CFG_WSUB_HERM("cols480_10x6x8_ws", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 16, 640, true, true, true, TW_LDS, 1, true),
     MIFFT_CFG_HERM("cols128_16x8_w32", float, MIFFT_F32, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 4, false),
@@ -454,7 +454,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols || e.tstore) return false;
         if (e.herm && !pass.want_herm) return false;  // Hermitian twins: only where the scheduler asks for one
         if (!e.herm && pass.herm_only) return false;
-        if (e.herm && !herm_pays(plan, pass, e.tile)) return false;
+        if (e.herm && !herm_pays(plan, pass, e.tile, e.lds, e.threads)) return false;
         if (e.in_real != (pass.first && plan.in_components == 1)) return false;
         if (e.stream_pref == 1 && !streaming) return false;
         if (e.stream_pref == 2 && !(plan.cache_resident_nd && pass.first)) return false;
@@ -473,11 +473,8 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         pass.lds_bytes = e.lds;
         pass.ld = (int)pass.N;
         pass.wg_per_cu = grid_per_cu_of(e.name);
-        pass.herm_d1 = pass.herm_d2 = 0;
-        if (e.herm) {  // trailing dimensions of the column space: (d1, d2), d1 = 1 for a 2-D plan
-            pass.herm_d2 = (int)plan.dims[plan.ndim - 1];
-            pass.herm_d1 = plan.ndim == 3 ? (int)plan.dims[1] : 1;
-        }
+        pass.herm_d0 = pass.herm_d1 = pass.herm_d2 = 0;
+        if (e.herm) herm_set_dims(plan, pass);  // trailing dimensions of the column space
         return true;
     };
     for (const FastEntry& e : kFastTable)  // hand-tuned entries win

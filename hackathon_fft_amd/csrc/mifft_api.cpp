@@ -312,9 +312,9 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
         ps.radices = ordered[i];
         ps.processed = processed[i];
         ps.first = i == ndim - 1;
-        // the LAST pass of a real-input 2-D / 3-D plan may exploit the Hermitian symmetry of what it reads (TileCfg::HERM):
+        // the LAST pass of a real-input 2-D .. 4-D plan may exploit the Hermitian symmetry of what it reads (TileCfg::HERM):
         // half the reads and butterflies, every result stored at (k, c) and conjugated at (-k, -c)
-        ps.want_herm = cfg.herm && i == 0 && ndim >= 2 && ndim <= 3 && in_components == 1 && !(flags & MIFFT_FLAG_FAITHFUL_STAGES) &&
+        ps.want_herm = cfg.herm != 0 && i == 0 && ndim >= 2 && ndim <= 4 && in_components == 1 && !(flags & MIFFT_FLAG_FAITHFUL_STAGES) &&
                        ps.inner < (1ll << 30);
         bool ok = false;
         if (!(flags & MIFFT_FLAG_FAITHFUL_STAGES)) {
@@ -386,7 +386,7 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
             }
             if (!ok) ok = select_dpp_rows(p, ps);  // wave-shuffle radix 3 for N = 93 (negative result)
 #endif
-            // last pass of a real-input 2-D / 3-D plan: a Hermitian twin (half the columns) beats any full column kernel --
+            // last pass of a real-input 2-D .. 4-D plan: a Hermitian twin (half the columns) beats any full column kernel --
             // a tuned twin first, else the runtime-specialised one, and only then the ordinary tables
             if (!ok && ps.want_herm) {
                 ps.herm_only = true;

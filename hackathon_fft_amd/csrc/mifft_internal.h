@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -73,12 +74,12 @@ struct DimPass {
     void* d_aux3 = nullptr;           // TSTORE passes: [tile][N] table of W^(c*k1) for the columns of one tile
     bool reverse = false;             // in-place pass that walks its tiles last-to-first (TileParams::reverse)
     int wg_per_cu = 0;                // workgroups per CU of the persistent grid (0 = the LDS / wave-count formula)
-    // last pass of a real-input 2-D / 3-D plan: the kernel families may take a Hermitian twin (TileCfg::HERM) that reads
-    // and transforms only the columns up to their mirror.  want_herm is set by the scheduler, herm_d1 / herm_d2 (the
+    // last pass of a real-input 2-D .. 4-D plan: the kernel families may take a Hermitian twin (TileCfg::HERM) that reads
+    // and transforms only the columns up to their mirror.  want_herm is set by the scheduler, herm_d0 / herm_d1 / herm_d2 (the
     // trailing dimensions of the column space) by the family that selected such a kernel (0 = an ordinary kernel).
     bool want_herm = false;
     bool herm_only = false;  // (select_fast: accept only Hermitian twins -- the scheduler tries those first)
-    int herm_d1 = 0, herm_d2 = 0;
+    int herm_d0 = 0, herm_d1 = 0, herm_d2 = 0;
 };
 
 struct Plan {
@@ -110,19 +111,50 @@ struct Plan {
     size_t out_elem_bytes() const;  // bytes of one complex output element
 };
 
+// Hermitian twins: the trailing dimensions of the column space of the last pass (dims[1..ndim-1], at most three; absent
+// leading ones are 1), and the flat prefix of columns that are not beyond their own mirror image
+inline void herm_set_dims(const Plan& plan, DimPass& pass) {
+    const int n = plan.ndim;
+    pass.herm_d2 = (int)plan.dims[n - 1];
+    pass.herm_d1 = n >= 3 ? (int)plan.dims[n - 2] : 1;
+    pass.herm_d0 = n >= 4 ? (int)plan.dims[n - 3] : 1;
+}
+inline long long herm_prefix(int d0, int d1, int d2) {
+    if (d0 > 1) return (long long)(d0 / 2 + 1) * d1 * d2;
+    if (d1 > 1) return (long long)(d1 / 2 + 1) * d2;
+    return d2 / 2 + 1;
+}
+
 // Does a Hermitian twin (TileCfg::HERM) with `tile` columns per tile pay for this pass?  Measured with tools/herm_probe.py
 // (DESIGN_EXPERIMENTS.md R3.6):
 //   * tiles of whole 128-byte lines store their mirrored lines whole (contiguous runs with a carried column): 5-11 % of the
 //     whole transform at every size -- provided the rows of the trailing dimension are a whole number of tiles, or the
 //     tensor stays in the Infinity Cache, where the partial lines merge;
 //   * narrower tiles (strided dimensions beyond ~1024 points) store every mirrored line in pieces: a gain (3-15 %) only
-//     while the tensor is cache resident, and none at all for 4-column tiles.
-inline bool herm_pays(const Plan& plan, const DimPass& pass, int tile) {
+//     while the tensor is cache resident, and none at all for 4-column tiles;
+//   * a Hermitian tile stores twice what an ordinary one does, so half the tiles must also mean clearly fewer ROUNDS of the
+//     persistent grid: 1 x 64^4 (2112 tiles on 1024 workgroups: 3 rounds instead of 4) runs 12 % SLOWER, 1 x 256^3 (the
+//     same 3 : 4, but four times the arithmetic per stored line) 5 % faster, 4 x 64^4 (9 : 16) 6 % faster.
+inline bool herm_pays(const Plan& plan, const DimPass& pass, int tile, size_t lds_bytes, int threads) {
+    if (config().herm == 2) return true;  // (lab build only: forced)
     const double out_bytes = plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes();
     const bool resident = out_bytes <= (double)kInfinityCacheBytes;
     const long long d2 = plan.dims[plan.ndim - 1];
-    if ((long long)tile * (long long)plan.out_elem_bytes() >= 128) return d2 % tile == 0 || resident;
-    return resident && pass.N <= 2048;
+    if ((long long)tile * (long long)plan.out_elem_bytes() >= 128) {
+        if (d2 % tile != 0 && !resident) return false;
+    } else if (!resident || pass.N > 2048) {
+        return false;
+    }
+    DimPass dims = pass;
+    herm_set_dims(plan, dims);
+    long long per_cu = (160 * 1024) / (long long)(lds_bytes ? lds_bytes : 1);  // the persistent grid, as tile_grid<>
+    per_cu = std::max<long long>(1, std::min<long long>(std::min<long long>(per_cu, 2048 / (threads > 0 ? threads : 256)), 16));
+    const long long grid = (long long)plan.num_cus * per_cu;
+    const long long images = (long long)plan.size_batch() * pass.outer;
+    const long long full = images * ((pass.inner + tile - 1) / tile);
+    const long long half = images * ((herm_prefix(dims.herm_d0, dims.herm_d1, dims.herm_d2) + tile - 1) / tile);
+    const long long rounds_full = (full + grid - 1) / grid, rounds_half = (half + grid - 1) / grid;
+    return (double)rounds_half <= (pass.N >= 128 ? 0.75 : 0.70) * (double)rounds_full;
 }
 
 // kernel families; each returns true and fills pass.launch/tile/... when it

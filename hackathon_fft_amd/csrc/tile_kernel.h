@@ -126,7 +126,7 @@ struct TileParams {
     long long fs_n2;
     // HERM configurations (last pass of a REAL-input N-D plan, in place): the trailing dimensions (d1, d2) of the column
     // index space (d1 = 1 for a 2-D plan); tiles_per_outer covers only the flat prefix [0, (d1/2 + 1) * d2) of the columns
-    int herm_d1, herm_d2;
+    int herm_d0, herm_d1, herm_d2;  // HERM: the trailing dimensions of the column space (leading ones 1 when absent)
 };
 
 MIFFT_DEV long long tile_id(const TileParams& p, long long t) { return p.reverse ? p.n_tiles - 1 - t : t; }
@@ -648,10 +648,11 @@ MIFFT_DEV void pass_gather_lds(const TileParams& p, const cpx<typename C::T>* sr
     }
 }
 
-// HERM: the flat column (ky, kx) of the trailing dimensions (herm_d1 x herm_d2) mirrors to (-ky, -kx)
+// HERM: the flat column (kz, ky, kx) of the trailing dimensions (herm_d0 x herm_d1 x herm_d2) mirrors to (-kz, -ky, -kx)
 MIFFT_DEV int herm_mirror(const TileParams& p, int cf) {
-    const int d2 = p.herm_d2, ky = cf / d2, kx = cf - ky * d2;
-    return (ky ? p.herm_d1 - ky : 0) * d2 + (kx ? d2 - kx : 0);
+    const int d2 = p.herm_d2, d1 = p.herm_d1;
+    const int r = cf / d2, kx = cf - r * d2, kz = r / d1, ky = r - kz * d1;
+    return ((kz ? p.herm_d0 - kz : 0) * d1 + (ky ? d1 - ky : 0)) * d2 + (kx ? d2 - kx : 0);
 }
 
 // registers -> butterflies -> Stockham scatter (LDS, or HBM for the last pass)

@@ -20,7 +20,10 @@
  * the conjugate twiddles and scales each transformed dimension by 1/N_dim
  * (fft/fft/_fft.mojo:292-294), i.e. matches numpy.fft.fftn / ifftn over axes
  * 1..ndim.  A real input produces the FULL N-point spectrum
- * (fft/fft/_fft.mojo:254-257), not numpy's half spectrum.
+ * (fft/fft/_fft.mojo:254-257), not numpy's half spectrum.  (For real input with 2..4
+ * transformed dimensions the last pass may compute only half of the spectrum and store the
+ * other half as its conjugate mirror image -- the same values to rounding, exactly Hermitian;
+ * never with MIFFT_FLAG_FAITHFUL_STAGES.)
  *
  * Environment (read ONCE per process, at the first plan; hackathon_fft_amd/csrc/mifft_config.h):
  *     MIFFT_JIT=0           no runtime specialisation (hipRTC): lengths without a precompiled kernel run
@@ -31,7 +34,7 @@
  * Nothing else is configurable in libmifft.so: every size threshold of the plan-time policy is a
  * constant derived from the 256-MiB Infinity Cache (kInfinityCacheBytes).  The measurement switches the
  * scripts under tools/ use (MIFFT_ND_CACHE, MIFFT_NTS_*, MIFFT_FOURSTEP_*, MIFFT_FS_*, MIFFT_ROW2D,
- * MIFFT_JIT_NT, MIFFT_JIT_IMAGE, MIFFT_DPP, MIFFT_GRID_PER_CU) and the fault injection of the tests
+ * MIFFT_JIT_NT, MIFFT_JIT_IMAGE, MIFFT_DPP, MIFFT_HERM, MIFFT_GRID_PER_CU) and the fault injection of the tests
  * (MIFFT_TEST_FAIL_SCRATCH_ALLOC) exist only in the LAB build, libmifft_lab.so
  * (-DMIFFT_EXPERIMENTAL -DMIFFT_TESTING, same ABI), together with the experimental kernels that stayed
  * negative results; the host package loads it only when MIFFT_LIBRARY points at it.

@@ -81,3 +81,40 @@ def to_complex(a):
 
 def from_complex(c, dtype):
     return np.stack([c.real, c.imag], axis=-1).astype(dtype)
+
+
+def check_hermitian_plan(fft_fn, shape, dtype, inverse, oracle=None):
+    """Real input through a plan whose LAST pass is a Hermitian twin (kernel name `..._h`): parity with fp64 pocketfft (and
+    the oracle when given), Y[-k, -c] == conj(Y[k, c]) BIT FOR BIT wherever one of the two was stored as the conjugate of the
+    other, and agreement to rounding with the complex-input plan on (x, 0), which runs the ordinary kernels.
+    fft_fn(x, inverse=, out_dtype=) -> (out, plan)."""
+    rng = np.random.default_rng(sum(shape) + int(inverse))
+    x = rng.standard_normal(shape + (1,)).astype(dtype)
+    out, plan = fft_fn(x, inverse=inverse, out_dtype=dtype)
+    assert plan.kernel_name(0).endswith(("_h", "_h_jit")), plan.kernel_name(0)
+    assert not np.isnan(out).any()
+    axes = tuple(range(1, len(shape)))
+    z = x[..., 0].astype(np.float64)
+    truth = np.fft.ifftn(z, axes=axes) if inverse else np.fft.fftn(z, axes=axes)
+    assert rel_l2(out, from_complex(truth, np.float64)) < (REL_L2_TOL_F32 if dtype == np.float32 else 1e-11)
+    del truth, z
+    if oracle is not None:
+        assert rel_l2(out, oracle(x, inverse=inverse, out_dtype=dtype)) < (REL_L2_TOL_F32 if dtype == np.float32 else REL_L2_TOL_F64)
+    # a column c (index over the trailing dimensions) that is its own mirror image is transformed on its own: Hermitian along
+    # k to rounding only
+    y = out[..., 0] + 1j * out[..., 1]
+    mirrored = y
+    self_col = np.ones(shape[2:], dtype=bool)
+    for ax in axes:
+        mirrored = np.roll(np.flip(mirrored, axis=ax), 1, axis=ax)
+        if ax >= 2:
+            n = shape[ax]
+            k = np.arange(n)
+            self_col = self_col & (k == (n - k) % n).reshape([-1 if a == ax - 2 else 1 for a in range(len(shape) - 2)])
+    assert np.array_equal(np.conj(mirrored)[:, :, ~self_col], y[:, :, ~self_col])
+    assert np.abs(np.conj(mirrored) - y).max() <= 2e-5 * np.abs(y).max()
+    del mirrored, y
+    xc = np.concatenate([x, np.zeros_like(x)], axis=-1)
+    outc, planc = fft_fn(xc, inverse=inverse, out_dtype=dtype)
+    assert not planc.kernel_name(0).endswith(("_h", "_h_jit"))
+    assert rel_l2(out, outc) < (2e-6 if dtype == np.float32 else 1e-12)

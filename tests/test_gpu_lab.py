@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REL_L2_TOL_F32, ROOT, from_complex, rel_l2, to_complex
+from conftest import REL_L2_TOL_F32, ROOT, check_hermitian_plan, from_complex, rel_l2, to_complex
 from oracle import mifft_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -137,3 +137,27 @@ def test_dpp_radix3_rows(shape, inverse, monkeypatch):
     if shape[0] >= 16:
         part, _ = lab_fft(x, inverse=inverse, first=5, count=7)
         assert np.array_equal(part[5:12], out[5:12]) and np.isnan(part[:5]).all() and np.isnan(part[12:]).all()
+
+
+@pytest.mark.parametrize("shape,dtype", [((3, 640, 480), np.float32), ((2, 480, 640), np.float32), ((2, 128, 128, 128), np.float32),
+                                         ((3, 64, 64, 64), np.float32),
+                                         ((4, 640, 50), np.float32),      # ragged last column tile
+                                         ((3, 270, 333), np.float32),     # odd lengths: no self-mirrored middle column
+                                         ((2, 12, 10, 21), np.float32),   # tiles across the rows of the trailing dimensions
+                                         ((1, 1920, 200), np.float32),    # 8-column tiles: no carried column
+                                         ((2, 360, 280), np.float64), ((2, 20, 24, 28), np.float64),
+                                         ((1, 64, 16, 8, 64), np.float32), ((2, 12, 5, 6, 14), np.float32),  # three trailing dimensions
+                                         ((400, 640, 48), np.float32)])   # runs of several tiles per workgroup across images
+@pytest.mark.parametrize("inverse", [False, True])
+def test_hermitian_twins_forced_on_small_shapes(shape, dtype, inverse, monkeypatch):
+    """MIFFT_HERM=2 takes the Hermitian twin of the last pass wherever one exists, also where the plan-time policy of the
+    product (herm_pays: fewer rounds of the persistent grid, whole-line tiles or a cache-resident tensor) would not: the
+    ragged, odd, tiny and row-crossing geometries of the mirrored stores and of the carried column."""
+    monkeypatch.setenv("MIFFT_HERM", "2")
+
+    def fft_fn(x, *, inverse, out_dtype):
+        assert x.dtype == out_dtype
+        return lab_fft(x, inverse=inverse)
+
+    small = np.prod(shape) <= 400000
+    check_hermitian_plan(fft_fn, shape, dtype, inverse, oracle=O.fftn if small else None)

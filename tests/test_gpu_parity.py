@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import hackathon_fft_amd as mf
-from conftest import (REF_ATOL, REF_RTOL, REL_L2_TOL_F32, REL_L2_TOL_F64, from_complex, load_matrix, rel_l2,
+from conftest import (REF_ATOL, check_hermitian_plan, REF_RTOL, REL_L2_TOL_F32, REL_L2_TOL_F64, from_complex, load_matrix, rel_l2,
                       to_complex)
 from oracle import mifft_oracle as O
 
@@ -210,50 +210,17 @@ def test_every_input_element_type_the_reference_casts(kind, comps, shape, faithf
             assert "_jit" in plan.kernel_name(len(shape) - 2), plan.kernel_name(len(shape) - 2)
 
 
-@pytest.mark.parametrize("shape,dtype", [((3, 640, 480), np.float32), ((2, 480, 640), np.float32), ((2, 128, 128, 128), np.float32),
-                                         ((3, 64, 64, 64), np.float32), ((1, 256, 256, 256), np.float32),
-                                         ((4, 640, 50), np.float32),      # ragged last column tile
-                                         ((3, 270, 333), np.float32),     # odd lengths: no self-mirrored middle column
-                                         ((2, 12, 10, 21), np.float32), ((1, 1920, 200), np.float32),   # (8-column tiles: no carried column)
-                                          ((2, 360, 280), np.float64), ((2, 20, 24, 28), np.float64)])
+@pytest.mark.parametrize("shape,dtype", [((25, 640, 480), np.float32), ((50, 64, 64, 64), np.float32), ((10, 128, 128, 128), np.float32),
+                                         ((1, 256, 256, 256), np.float32), ((30, 360, 280), np.float64),
+                                         ((10, 1920, 1080), np.float32),      # 8-column tiles: no carried column
+                                         ((2, 64, 64, 64, 64), np.float32)])  # three trailing dimensions
 @pytest.mark.parametrize("inverse", [False, True])
 def test_last_pass_of_real_input_plans_uses_the_hermitian_symmetry(shape, dtype, inverse):
-    """Real input, 2-D / 3-D: the last (strided, in-place) pass transforms only the columns up to their mirror and stores
+    """Real input, 2-D .. 4-D: the last (strided, in-place) pass transforms only the columns up to their mirror and stores
     every result twice, at (k, c) and conjugated at (-k, -c) (TileCfg::HERM; the reference computes all of it,
-    fft/fft/_ndim_fft_gpu.mojo:634-642).  Parity with the oracle / pocketfft as for every other kernel, the spectrum is now
-    EXACTLY Hermitian, and the complex-input plan of (x, 0) agrees to rounding."""
-    rng = np.random.default_rng(sum(shape) + int(inverse))
-    x = rng.standard_normal(shape + (1,)).astype(dtype)
-    out, plan = gpu_fft(x, inverse=inverse, out_dtype=dtype)
-    assert plan.kernel_name(0).endswith("_h") or plan.kernel_name(0).endswith("_h_jit"), plan.kernel_name(0)
-    assert not np.isnan(out).any()
-    axes = tuple(range(1, len(shape)))
-    z = x[..., 0].astype(np.float64)
-    truth = np.fft.ifftn(z, axes=axes) if inverse else np.fft.fftn(z, axes=axes)
-    tol = REL_L2_TOL_F32 if dtype == np.float32 else 1e-11
-    assert rel_l2(out, from_complex(truth, np.float64)) < tol
-    if np.prod(shape) <= 200000:
-        assert rel_l2(out, O.fftn(x, inverse=inverse, out_dtype=dtype)) < (REL_L2_TOL_F32 if dtype == np.float32 else REL_L2_TOL_F64)
-    # Y[-k, -c] == conj(Y[k, c]) BIT FOR BIT for every column c (index over the trailing dimensions) that is not its own
-    # mirror -- one of the two was stored as the conjugate of the other; a self-mirrored column is transformed on its own and
-    # is Hermitian along k to rounding
-    y = out[..., 0] + 1j * out[..., 1]
-    mirrored = y
-    self_col = np.ones(shape[2:], dtype=bool)
-    for ax in axes:
-        mirrored = np.roll(np.flip(mirrored, axis=ax), 1, axis=ax)
-        if ax >= 2:
-            n = shape[ax]
-            k = np.arange(n)
-            self_col = self_col & (k == (n - k) % n).reshape([-1 if a == ax - 2 else 1 for a in range(len(shape) - 2)])
-    assert np.array_equal(np.conj(mirrored)[:, :, ~self_col], y[:, :, ~self_col])
-    scale = np.abs(y).max()
-    assert np.abs(np.conj(mirrored) - y).max() <= 2e-5 * scale
-    # the complex plan on (x, 0) runs the ordinary kernels
-    xc = np.concatenate([x, np.zeros_like(x)], axis=-1)
-    outc, planc = gpu_fft(xc, inverse=inverse, out_dtype=dtype)
-    assert not planc.kernel_name(0).endswith(("_h", "_h_jit"))
-    assert rel_l2(out, outc) < (2e-6 if dtype == np.float32 else 1e-12)
+    fft/fft/_ndim_fft_gpu.mojo:634-642).  Shapes large enough for the plan-time policy (herm_pays, mifft_internal.h) to take
+    the twin; tests/test_gpu_lab.py forces it on small, ragged and odd shapes.  Checks: conftest.check_hermitian_plan."""
+    check_hermitian_plan(gpu_fft, shape, dtype, inverse)
 
 
 def test_batch_range_and_untouched_rows():
