@@ -21,6 +21,7 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
     tp.thi = pass.d_aux2;
     tp.tcol = pass.d_aux3;
     tp.reverse = pass.reverse;
+    tp.store_lim = pass.store_lim;  // (HS configurations)
     if (C::COLS) {
         tp.inner = pass.inner;
         tp.tiles_per_outer = (pass.inner + C::TILE - 1) / C::TILE;
@@ -77,6 +78,7 @@ struct FastEntry {
     int tile, threads;
     size_t lds;
     bool herm = false;  // TileCfg::HERM twin: last (strided, in-place) pass of a real-input 2-D .. 4-D plan
+    bool hs = false;    // TileCfg::HS twin: the pass before it, storing only the lower half of its dimension
 };
 
 #define MIFFT_TILECFG(TS, REAL, NTM, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF) \
@@ -101,6 +103,19 @@ struct FastEntry {
             TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, false, false, 0, false, T, WS, false, 0, true>::LDS_BYTES,     \
             true                                                                                                                           \
     }
+// half-store twin (TileCfg::HS) of a row / column configuration: REAL = promotes a real tensor, NTM = non-temporal mode,
+// STREAM = stream_pref of the entry
+#define MIFFT_HS_TILECFG(REAL, NTM, WS, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF) \
+    TileCfg<T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF, 0, REAL, false, NTM, false, T, WS, false, 0, false, true>
+#define MIFFT_CFG_HS_X(REAL, NTM, STREAM, WS, NAME, T, DT, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)                \
+    {                                                                                                                                      \
+        false, REAL, STREAM, DT, N, COLS, NAME "_hs",                                                                                      \
+            launch_tile<MIFFT_HS_TILECFG(REAL, NTM, WS, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)>,            \
+            prepare_tile<MIFFT_HS_TILECFG(REAL, NTM, WS, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)>,           \
+            TILE, THREADS,                                                                                                                 \
+            MIFFT_HS_TILECFG(REAL, NTM, WS, T, N, NP, R0, R1, R2, R3, TILE, THREADS, COLS, FD, LD_, TWM, MINW, PF)::LDS_BYTES, false, true   \
+    }
+#define MIFFT_CFG_HS(...) MIFFT_CFG_HS_X(false, 0, -1, false, __VA_ARGS__)
 #define MIFFT_CFG_HERM(...) MIFFT_CFG_HERM_X(false, __VA_ARGS__)
 #define MIFFT_CFG_WSUB_HERM(...) MIFFT_CFG_HERM_X(true, __VA_ARGS__)
 // column tile whose passes 1..NP-1 run inside wave-owned sub-problems (TileCfg::WSUB): R0 a multiple of THREADS / 64

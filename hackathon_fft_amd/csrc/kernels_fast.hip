@@ -90,6 +90,18 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_HERM("cols64_8x8_w32", float, MIFFT_F32, 64, 2, 8, 8, 1, 1, 32, 256, true, true, true, TW_LDS, 2, false),
     MIFFT_CFG_HERM("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG_HERM("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, true, TW_LDS, 2, false),
+    // half-store twins (the pass before a Hermitian last pass stores only the lower half of its dimension; taken only
+    // when the scheduler asks for one): the row pass of a real-input 2-D plan, the middle column pass of a 3-D / 4-D one
+    MIFFT_CFG_HS_X(true, 1, 2, false, "rows480_10x6x8_r_ntl", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_HS_X(true, 0, -1, false, "rows480_10x6x8_r", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_HS_X(true, 1, 2, false, "rows640_10x8x8_r_ntl", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_HS_X(true, 0, -1, false, "rows640_10x8x8_r", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    MIFFT_CFG_HS("cols128_16x8_w32", float, MIFFT_F32, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 4, false),
+    MIFFT_CFG_HS("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
+    MIFFT_CFG_HS("cols64_8x8_w64", float, MIFFT_F32, 64, 2, 8, 8, 1, 1, 64, 512, true, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_HS("cols64_8x8_w32", float, MIFFT_F32, 64, 2, 8, 8, 1, 1, 32, 256, true, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_HS("cols64_4x4x4", float, MIFFT_F32, 64, 3, 4, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
+    MIFFT_CFG_HS("cols256_16x16", float, MIFFT_F32, 256, 2, 16, 16, 1, 1, 16, 256, true, true, true, TW_LDS, 2, false),
     MIFFT_CFG_WSUB("cols640_10x8x8_ws", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 16, 640, true, true, true, TW_LDS, 1, true),
     MIFFT_CFG_WSUB("cols480_10x6x8_ws", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 16, 640, true, true, true, TW_LDS, 1, true),
     // 16 columns x 1024 points = 128 KiB: the four-step passes of 2^20-point transforms (0.266 vs 0.349 ms for
@@ -174,6 +186,7 @@ static int launch_plane(const Plan& plan, const DimPass& pass, const void* in, v
     tp.n_rows = 0;
     tp.n_tiles = count * pass.outer;  // planes
     tp.reverse = pass.reverse;
+    tp.store_lim = pass.store_lim;  // (HS column sides)
     auto k = plane_kernel<CR, CC>;
     const long long grid = tile_grid<CR>(plan.num_cus, tp.n_tiles, pass.wg_per_cu);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(CR::THREADS), CR::LDS_BYTES, stream, tp);
@@ -198,6 +211,7 @@ static int launch_plane_wp(const Plan& plan, const DimPass& pass, const void* in
     tp.tiles_per_outer = 1;
     tp.n_tiles = count * pass.outer;  // planes
     tp.reverse = pass.reverse;
+    tp.store_lim = pass.store_lim;  // (HS column sides)
     long long per_cu = (160 * 1024) / (long long)G::LDS_BYTES;
     if (per_cu > 2048 / CR::THREADS) per_cu = 2048 / CR::THREADS;
     if (per_cu < 1) per_cu = 1;
@@ -277,6 +291,7 @@ struct PlaneEntry {
     int (*prepare)();
     int threads;
     size_t lds;
+    bool hs = false;  // the column side stores only rows 0 .. N1 / 2 of the plane (TileCfg::HS): a Hermitian pass follows
 };
 
 // rows configuration (N2, TILE = N1, HBM -> LDS) then columns configuration (N1, TILE = N2, LDS -> HBM).
@@ -300,6 +315,9 @@ using Plane128WCS = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, true, false, 
 // real-input twins (C_in = 1 promoted in the pass-0 load)
 using Plane64RR = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, false, true, false, TW_LDS, 2, false, 0, true>;
 using Plane128WRR = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, false, true, false, TW_LDS, 4, true, 0, true>;
+// half-store column sides (the plane of a real-input 3-D plan whose last pass is a Hermitian twin)
+using Plane64CH = TileCfg<float, 64, 2, 8, 8, 1, 1, 64, 512, true, false, true, TW_LDS, 2, false, 0, false, false, 0, false, float, false, false, 0, false, true>;
+using Plane128WCH = TileCfg<float, 128, 2, 8, 16, 1, 1, 128, 1024, true, false, true, TW_LDS, 4, false, 0, false, false, 0, false, float, false, false, 0, false, true>;
 
 static const PlaneEntry kPlaneTable[] = {
     {true, false, false, MIFFT_F32, 64, 64, "plane64x64_8x8_ntl", launch_plane<Plane64RN, Plane64C>,
@@ -308,6 +326,8 @@ static const PlaneEntry kPlaneTable[] = {
      512, Plane64R::LDS_BYTES},
     {false, false, false, MIFFT_F32, 64, 64, "plane64x64_8x8", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>,
      512, Plane64R::LDS_BYTES},
+    {false, false, true, MIFFT_F32, 64, 64, "plane64x64_8x8_r_hs", launch_plane<Plane64RR, Plane64CH>, prepare_plane<Plane64RR, Plane64CH>,
+     512, Plane64RR::LDS_BYTES, true},
     {false, false, true, MIFFT_F32, 64, 64, "plane64x64_8x8_r", launch_plane<Plane64RR, Plane64C>, prepare_plane<Plane64RR, Plane64C>,
      512, Plane64RR::LDS_BYTES},
     // wave-private exchanges (plane_kernel_wp): 2 workgroup barriers per plane instead of 12; 1280 planes 0.0812 ->
@@ -320,6 +340,8 @@ static const PlaneEntry kPlaneTable[] = {
      prepare_plane_wp<Plane128WR, Plane128WCS, 8>, 1024, WavePlane<Plane128WR, Plane128WCS, 8>::LDS_BYTES},
     {false, false, false, MIFFT_F32, 128, 128, "plane128x128_8x16_wp", launch_plane_wp<Plane128WR, Plane128WC, 8>,
      prepare_plane_wp<Plane128WR, Plane128WC, 8>, 1024, WavePlane<Plane128WR, Plane128WC, 8>::LDS_BYTES},
+    {false, false, true, MIFFT_F32, 128, 128, "plane128x128_8x16_wp_r_hs", launch_plane_wp<Plane128WRR, Plane128WCH, 8>,
+     prepare_plane_wp<Plane128WRR, Plane128WCH, 8>, 1024, WavePlane<Plane128WRR, Plane128WCH, 8>::LDS_BYTES, true},
     {false, false, true, MIFFT_F32, 128, 128, "plane128x128_8x16_wp_r", launch_plane_wp<Plane128WRR, Plane128WC, 8>,
      prepare_plane_wp<Plane128WRR, Plane128WC, 8>, 1024, WavePlane<Plane128WRR, Plane128WC, 8>::LDS_BYTES},
 };
@@ -329,6 +351,7 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
     for (const PlaneEntry& e : kPlaneTable) {
         if (e.out_dtype != plan.out_dtype || e.N2 != pass.N || e.N1 != pass.N1) continue;
         if (e.in_real != (pass.first && plan.in_components == 1)) continue;
+        if (e.hs != pass.want_half) continue;
         if (e.ntl && !(plan.cache_resident_nd && plan.ndim > 2)) continue;  // a 2-D plane is the only pass: nothing to keep
         if (e.ntl && e.N1 == 128 &&
             plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes() < config().nd_plane128_min_bytes)
@@ -342,6 +365,7 @@ bool select_fast_plane(const Plan& plan, DimPass& pass) {
         pass.threads = e.threads;
         pass.lds_bytes = e.lds;
         pass.ld = (int)pass.N;
+        pass.hs = e.hs;
         return true;
     }
     return false;
@@ -453,6 +477,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
     auto try_entry = [&](const FastEntry& e) {
         if (e.out_dtype != plan.out_dtype || e.N != pass.N || e.cols != cols || e.tstore) return false;
         if (e.herm && !pass.want_herm) return false;  // Hermitian twins: only where the scheduler asks for one
+        if (e.hs != pass.want_half) return false;       // half-store twins likewise, and nothing else when it does
         if (!e.herm && pass.herm_only) return false;
         if (e.herm && !herm_pays(plan, pass, e.tile, e.lds, e.threads)) return false;
         if (e.in_real != (pass.first && plan.in_components == 1)) return false;
@@ -473,6 +498,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         pass.lds_bytes = e.lds;
         pass.ld = (int)pass.N;
         pass.wg_per_cu = grid_per_cu_of(e.name);
+        pass.hs = e.hs;
         pass.herm_d0 = pass.herm_d1 = pass.herm_d2 = 0;
         if (e.herm) herm_set_dims(plan, pass);  // trailing dimensions of the column space
         return true;

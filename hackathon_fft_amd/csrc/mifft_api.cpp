@@ -301,6 +301,40 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
         }
         return e;
     };
+    // Will the LAST pass (dimension 0) be a Hermitian twin?  Asked when the pass over dimension 1 is selected: that pass may
+    // then store only the lower half of its dimension (TileCfg::HS).  The same selection the loop below makes for i == 0,
+    // on a scratch DimPass (whatever it uploads is freed again); the loop checks at the end that both agree.
+    int herm_known = -1;
+    auto last_pass_will_be_hermitian = [&]() -> bool {
+        if (herm_known >= 0) return herm_known != 0;
+        herm_known = 0;
+        if (cfg.herm == 0 || !cfg.half_store || ndim < 2 || ndim > 4 || in_components != 1 || (flags & MIFFT_FLAG_FAITHFUL_STAGES)) return false;
+        DimPass t;
+        t.dim_index = 0;
+        t.N = dims[0];
+        t.inner = 1;
+        for (int k = 1; k < ndim; ++k) t.inner *= dims[k];
+        t.outer = 1;
+        t.radices = ordered[0];
+        t.processed = processed[0];
+        t.first = false;
+        if (t.inner >= (1ll << 30)) return false;
+#ifdef MIFFT_EXPERIMENTAL  // (lab knob that sends long strided dimensions to the four-step before anything else)
+        if (cfg.fs_strided_min_n > 0 && t.N >= cfg.fs_strided_min_n) return false;
+#endif
+        t.want_herm = t.herm_only = true;
+        bool ok = select_fast(p, t);
+        t.herm_only = false;
+        if (!ok && t.N <= 4096) {
+            std::string why;
+            ok = select_jit(p, t, why) && t.herm_d2 > 0;
+        }
+        if (t.d_aux) (void)hipFree(t.d_aux);
+        if (t.d_aux2) (void)hipFree(t.d_aux2);
+        if (t.d_aux3) (void)hipFree(t.d_aux3);
+        herm_known = ok ? 1 : 0;
+        return ok;
+    };
     for (int i = ndim - 1; i >= 0; --i) {
         DimPass ps;
         ps.dim_index = i;
@@ -325,7 +359,15 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
                 pl.outer = 1;
                 for (int k = 0; k < i - 1; ++k) pl.outer *= dims[k];
                 std::string whyp;
-                bool fused = select_fast_plane(p, pl) || select_jit_plane(p, pl, whyp);
+                bool fused = false;
+                if (i - 1 == 1 && last_pass_will_be_hermitian()) {  // the plane's column side is dimension 1: half store
+                    DimPass t = pl;
+                    t.want_half = true;
+                    t.store_lim = (int)(dims[1] / 2);
+                    fused = select_fast_plane(p, t) || select_jit_plane(p, t, whyp);
+                    if (fused) pl = t;
+                }
+                if (!fused) fused = select_fast_plane(p, pl) || select_jit_plane(p, pl, whyp);
 #ifdef MIFFT_EXPERIMENTAL  // L2-resident image kernel: a documented negative result, lab builds only
                 if (!fused) fused = select_jit_image(p, pl, whyp);
 #endif
@@ -333,6 +375,18 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
                     ps = pl;
                     ok = true;
                     --i;  // dimension i-1 is covered by this pass
+                }
+            }
+            // the pass over dimension 1 of a plan whose last pass will be a Hermitian twin: a half-store kernel, tuned or
+            // runtime specialised, before anything else
+            if (!ok && i == 1 && ps.N <= 4096 && last_pass_will_be_hermitian()) {
+                DimPass t = ps;
+                t.want_half = true;
+                t.store_lim = (int)(dims[1] / 2);
+                std::string whyh;
+                if (select_fast(p, t) || select_jit(p, t, whyh)) {
+                    ps = t;
+                    ok = true;
                 }
             }
             if (!ok) ok = select_row2d(p, ps);  // 16384-point rows: four-step inside one LDS plane, one launch
@@ -453,6 +507,16 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
             free_plan_device(p);
             delete h;
             return hip_error(e, "twiddle table upload");
+        }
+    }
+    {   // a half-store pass is only right in front of a Hermitian last pass (both selections are deterministic; this is the
+        // net under them)
+        bool any_hs = false;
+        for (const DimPass& q : p.passes) any_hs = any_hs || q.hs;
+        if (any_hs && !(p.passes.back().herm_d2 > 0)) {
+            free_plan_device(p);
+            delete h;
+            return set_error(MIFFT_ERR_HIP, "internal: half-store pass without a Hermitian last pass");
         }
     }
     if (nd_mode & 2) {

@@ -80,6 +80,11 @@ struct DimPass {
     bool want_herm = false;
     bool herm_only = false;  // (select_fast: accept only Hermitian twins -- the scheduler tries those first)
     int herm_d0 = 0, herm_d1 = 0, herm_d2 = 0;
+    // the pass BEFORE such a last pass (it transforms dims[1], the dimension the Hermitian pass halves; a plane: its column
+    // side) may store only the results 0 .. store_lim = dims[1] / 2 (TileCfg::HS): want_half asks the families for such a
+    // kernel ONLY, `hs` says the selected kernel is one
+    bool want_half = false, hs = false;
+    int store_lim = 0;
 };
 
 struct Plan {

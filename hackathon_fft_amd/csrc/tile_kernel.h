@@ -127,6 +127,9 @@ struct TileParams {
     // HERM configurations (last pass of a REAL-input N-D plan, in place): the trailing dimensions (d1, d2) of the column
     // index space (d1 = 1 for a 2-D plan); tiles_per_outer covers only the flat prefix [0, (d1/2 + 1) * d2) of the columns
     int herm_d0, herm_d1, herm_d2;  // HERM: the trailing dimensions of the column space (leading ones 1 when absent)
+    // HS configurations (the pass BEFORE a HERM last pass; a plane: its column side): results with an output index above
+    // store_lim are not stored -- the last pass reads only the half of that dimension up to its middle and writes the rest
+    int store_lim;
 };
 
 MIFFT_DEV long long tile_id(const TileParams& p, long long t) { return p.reverse ? p.n_tiles - 1 - t : t; }
@@ -213,7 +216,7 @@ constexpr int rader_lds_elems(int R, int inst, int esz) {
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
           bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false, typename IT_ = T_, bool WSUB_ = false,
-          bool FS1_ = false, int RADERM_ = 0, bool HERM_ = false>
+          bool FS1_ = false, int RADERM_ = 0, bool HERM_ = false, bool HS_ = false>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -310,6 +313,11 @@ struct TileCfg {
     // Half the reads and butterflies of the pass; the reference computes (and this library's other kernels compute) all of it.
     static constexpr bool HERM = HERM_;
     static_assert(!HERM_ || (COLS_ && LAST_DIRECT_ && !TSTORE_ && !FS1_), "HERM: a direct in-place column tile");
+    // HS ("half store"): the pass that transforms the dimension a following HERM pass halves -- the one before the last of a
+    // real-input N-D plan -- stores only the results 0 .. store_lim (= N / 2) of every transform: the HERM pass reads nothing
+    // else and writes every other point itself.  Half the writes of that pass.
+    static constexpr bool HS = HS_;
+    static_assert(!HS_ || (!TSTORE_ && !FS1_ && !HERM_), "HS: a plain row / column tile or the column side of a plane");
     static_assert(!FS1_ || (COLS_ && FIRST_DIRECT_ && LAST_DIRECT_ && !TSTORE_ && !WSUB_), "FS1: a direct column tile");
     static constexpr int CPITCH = TSTORE_ ? TILE_ + 1 : TILE_;
     static_assert(!TSTORE_ || (COLS_ && !LAST_DIRECT_ && FIRST_DIRECT_), "TSTORE: column tile, last pass left in LDS");
@@ -757,7 +765,7 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
                             y.x *= (T)p.scale;
                             y.y *= -(T)p.scale;
                         }
-                        gstore<(C::NT & 2) != 0>(gout + base + s * step + off, y);
+                        if (!C::HS || o0 + s * P <= p.store_lim) gstore<(C::NT & 2) != 0>(gout + base + s * step + off, y);
                     }
                 }
             } else {
@@ -1344,7 +1352,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             V* gout = (V*)p.out;
             for (int f = tid; f < C::N * C::TILE; f += C::THREADS) {
                 const int n = f / C::TILE, c = f - n * C::TILE;
-                if (c < nv) {
+                if (c < nv && (!C::HS || n <= p.store_lim)) {
                     V y = lds[lds_index<C, C::NP - 1>(c, n)];
                     if (p.inverse) {
                         y.x *= (T)p.scale;
@@ -1359,6 +1367,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             const int total = nv * C::N;
             for (int f = tid; f < total; f += C::THREADS) {
                 const int c = f / C::N, n = f - c * C::N;
+                if (C::HS && n > p.store_lim) continue;
                 V y = lds[lds_index<C, C::NP - 1>(c, n)];
                 if (p.inverse) {
                     y.x *= (T)p.scale;
@@ -1656,7 +1665,7 @@ MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long
                     y.x *= (T)p.scale;
                     y.y *= -(T)p.scale;
                 }
-                gstore<(CC::NT & 2) != 0>(gout + base + (long long)s * P * G::N2 + off, y);
+                if (!CC::HS || o0 + s * P <= p.store_lim) gstore<(CC::NT & 2) != 0>(gout + base + (long long)s * P * G::N2 + off, y);
             }
         }
     } else if constexpr (I < CC::NP) {
@@ -1703,7 +1712,8 @@ MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long
                         y.x *= (T)p.scale;
                         y.y *= -(T)p.scale;
                     }
-                    gstore<(CC::NT & 2) != 0>(gout + base + (long long)s * P * G::N2 + off, y);
+                    if (!CC::HS || o0 + s * P <= p.store_lim)
+                        gstore<(CC::NT & 2) != 0>(gout + base + (long long)s * P * G::N2 + off, y);
                 }
             } else {
 #pragma unroll

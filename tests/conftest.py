@@ -84,7 +84,8 @@ def from_complex(c, dtype):
 
 
 def check_hermitian_plan(fft_fn, shape, dtype, inverse, oracle=None):
-    """Real input through a plan whose LAST pass is a Hermitian twin (kernel name `..._h`): parity with fp64 pocketfft (and
+    """Real input through a plan whose LAST pass is a Hermitian twin (kernel name `..._h`) behind a half-store pass
+    (`..._hs`): parity with fp64 pocketfft (and
     the oracle when given), Y[-k, -c] == conj(Y[k, c]) BIT FOR BIT wherever one of the two was stored as the conjugate of the
     other, and agreement to rounding with the complex-input plan on (x, 0), which runs the ordinary kernels.
     fft_fn(x, inverse=, out_dtype=) -> (out, plan)."""
@@ -92,6 +93,8 @@ def check_hermitian_plan(fft_fn, shape, dtype, inverse, oracle=None):
     x = rng.standard_normal(shape + (1,)).astype(dtype)
     out, plan = fft_fn(x, inverse=inverse, out_dtype=dtype)
     assert plan.kernel_name(0).endswith(("_h", "_h_jit")), plan.kernel_name(0)
+    # ... and the pass before it stores only the half of dimension 1 that the last pass reads (TileCfg::HS)
+    assert "_hs" in plan.kernel_name(1), plan.kernel_name(1)
     assert not np.isnan(out).any()
     axes = tuple(range(1, len(shape)))
     z = x[..., 0].astype(np.float64)
