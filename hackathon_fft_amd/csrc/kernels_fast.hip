@@ -499,6 +499,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         pass.ld = (int)pass.N;
         pass.wg_per_cu = grid_per_cu_of(e.name);
         pass.hs = e.hs;
+        pass.regime_twin = e.stream_pref > 0;
         pass.herm_d0 = pass.herm_d1 = pass.herm_d2 = 0;
         if (e.herm) herm_set_dims(plan, pass);  // trailing dimensions of the column space
         return true;

@@ -305,10 +305,14 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
     // then store only the lower half of its dimension (TileCfg::HS).  The same selection the loop below makes for i == 0,
     // on a scratch DimPass (whatever it uploads is freed again); the loop checks at the end that both agree.
     int herm_known = -1;
+    auto herm_possible = [&]() -> bool {
+        return cfg.herm != 0 && cfg.half_store && ndim >= 2 && ndim <= 4 && in_components == 1 && !(flags & MIFFT_FLAG_FAITHFUL_STAGES);
+    };
+    // (asked ONCE, after p.hs_selected has been set: a half-store pass in front widens the cases in which the twin pays)
     auto last_pass_will_be_hermitian = [&]() -> bool {
         if (herm_known >= 0) return herm_known != 0;
         herm_known = 0;
-        if (cfg.herm == 0 || !cfg.half_store || ndim < 2 || ndim > 4 || in_components != 1 || (flags & MIFFT_FLAG_FAITHFUL_STAGES)) return false;
+        if (!herm_possible()) return false;
         DimPass t;
         t.dim_index = 0;
         t.N = dims[0];
@@ -360,12 +364,14 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
                 for (int k = 0; k < i - 1; ++k) pl.outer *= dims[k];
                 std::string whyp;
                 bool fused = false;
-                if (i - 1 == 1 && last_pass_will_be_hermitian()) {  // the plane's column side is dimension 1: half store
+                if (i - 1 == 1 && herm_possible()) {  // the plane's column side is dimension 1: half store
                     DimPass t = pl;
                     t.want_half = true;
                     t.store_lim = (int)(dims[1] / 2);
-                    fused = select_fast_plane(p, t) || select_jit_plane(p, t, whyp);
+                    p.hs_selected = select_fast_plane(p, t) || select_jit_plane(p, t, whyp);
+                    fused = p.hs_selected && last_pass_will_be_hermitian();
                     if (fused) pl = t;
+                    p.hs_selected = fused;
                 }
                 if (!fused) fused = select_fast_plane(p, pl) || select_jit_plane(p, pl, whyp);
 #ifdef MIFFT_EXPERIMENTAL  // L2-resident image kernel: a documented negative result, lab builds only
@@ -379,14 +385,29 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
             }
             // the pass over dimension 1 of a plan whose last pass will be a Hermitian twin: a half-store kernel, tuned or
             // runtime specialised, before anything else
-            if (!ok && i == 1 && ps.N <= 4096 && last_pass_will_be_hermitian()) {
+            // (a kernel tuned for a size regime -- a non-temporal twin -- is not traded for a runtime-specialised one: 64 x 1024^2
+            //  0.372 -> 0.422 ms with `rows1024_16x8x8_hs_r_jit` in place of `rows1024_16x8x8_r_nt`)
+            if (!ok && i == 1 && herm_possible()) {
                 DimPass t = ps;
                 t.want_half = true;
                 t.store_lim = (int)(dims[1] / 2);
-                std::string whyh;
-                if (select_fast(p, t) || select_jit(p, t, whyh)) {
+                bool found = select_fast(p, t);
+                if (!found && ps.N <= 4096) {
+                    DimPass u = ps;
+                    const bool tuned = select_fast(p, u) && u.regime_twin;
+                    std::string whyh;
+                    found = !tuned && select_jit(p, t, whyh);
+                }
+                p.hs_selected = found;
+                if (found && last_pass_will_be_hermitian()) {
                     ps = t;
                     ok = true;
+                } else {
+                    if (found) {  // (nothing but Rader tables could have been uploaded for t)
+                        if (t.d_aux) (void)hipFree(t.d_aux);
+                        if (t.d_aux2) (void)hipFree(t.d_aux2);
+                    }
+                    p.hs_selected = false;
                 }
             }
             if (!ok) ok = select_row2d(p, ps);  // 16384-point rows: four-step inside one LDS plane, one launch

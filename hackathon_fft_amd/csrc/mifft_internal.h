@@ -85,6 +85,8 @@ struct DimPass {
     // kernel ONLY, `hs` says the selected kernel is one
     bool want_half = false, hs = false;
     int store_lim = 0;
+    bool regime_twin = false;  // select_fast took an entry tuned for a size regime (non-temporal twin): not to be traded for
+                               // a runtime-specialised half-store kernel
 };
 
 struct Plan {
@@ -112,6 +114,9 @@ struct Plan {
     // N-D transform whose `out` tensor fits the 256-MiB Infinity Cache: the first pass reads x with non-temporal loads
     // (x does not displace the row results) and later in-place passes alternate their walking direction
     bool cache_resident_nd = false;
+    // plan creation only: the pass over dimension 1 has been given a half-store kernel (TileCfg::HS), which widens the cases
+    // in which a Hermitian last pass pays (herm_pays)
+    bool hs_selected = false;
     size_t in_elem_bytes() const;
     size_t out_elem_bytes() const;  // bytes of one complex output element
 };
@@ -131,12 +136,14 @@ inline long long herm_prefix(int d0, int d1, int d2) {
 }
 
 // Does a Hermitian twin (TileCfg::HERM) with `tile` columns per tile pay for this pass?  Measured with tools/herm_probe.py
-// (DESIGN_EXPERIMENTS.md R3.6):
-//   * tiles of whole 128-byte lines store their mirrored lines whole (contiguous runs with a carried column): 5-11 % of the
-//     whole transform at every size -- provided the rows of the trailing dimension are a whole number of tiles, or the
-//     tensor stays in the Infinity Cache, where the partial lines merge;
-//   * narrower tiles (strided dimensions beyond ~1024 points) store every mirrored line in pieces: a gain (3-15 %) only
-//     while the tensor is cache resident, and none at all for 4-column tiles;
+// (DESIGN_EXPERIMENTS.md R3.6), whole transform against the ordinary kernels:
+//   * tiles of whole 128-byte lines store their mirrored lines whole (contiguous runs with a carried column): 5-11 % at
+//     every size when the rows of the trailing dimension are a whole number of tiles; ragged rows leave every mirrored line
+//     in pieces (6 x 360^3 +3 %) unless the tensor stays in the Infinity Cache, where the pieces merge;
+//   * narrower tiles (strided dimensions beyond ~1024 points) store every mirrored line in pieces: alone a gain (3-15 %) only
+//     while the tensor is cache resident, and none at all for the 2-column tiles of 3840-point columns;
+//   * with a half-store pass in front (plan.hs_selected: that pass skips half its writes) the ragged and the 4- / 8-column cases
+//     pay beyond the cache too: 40 x 1920 x 1080 0.98 -> 0.91, 6 x 360^3 1.03 -> 0.93, 300 x 600 x 500 1.02 -> 0.95;
 //   * a Hermitian tile stores twice what an ordinary one does, so half the tiles must also mean clearly fewer ROUNDS of the
 //     persistent grid: 1 x 64^4 (2112 tiles on 1024 workgroups: 3 rounds instead of 4) runs 12 % SLOWER, 1 x 256^3 (the
 //     same 3 : 4, but four times the arithmetic per stored line) 5 % faster, 4 x 64^4 (9 : 16) 6 % faster.
@@ -145,9 +152,10 @@ inline bool herm_pays(const Plan& plan, const DimPass& pass, int tile, size_t ld
     const double out_bytes = plan.size_batch() * (double)plan.prod * (double)plan.out_elem_bytes();
     const bool resident = out_bytes <= (double)kInfinityCacheBytes;
     const long long d2 = plan.dims[plan.ndim - 1];
-    if ((long long)tile * (long long)plan.out_elem_bytes() >= 128) {
-        if (d2 % tile != 0 && !resident) return false;
-    } else if (!resident || pass.N > 2048) {
+    const long long run_bytes = (long long)tile * (long long)plan.out_elem_bytes();
+    if (run_bytes >= 128) {
+        if (d2 % tile != 0 && !resident && !plan.hs_selected) return false;
+    } else if (run_bytes < 32 || pass.N > 2048 || !(resident || plan.hs_selected)) {
         return false;
     }
     DimPass dims = pass;

@@ -352,7 +352,7 @@ struct TileCfg {
     static constexpr int STAGE_ELEMS = DMA_ ? N_ * TILE_ : 0;
     // HERM: one column of N results carried from a tile to the next one of the workgroup's run (see the HERM stores)
     // (full-line tiles only: narrower ones need the XCD_CHUNK order above -- their neighbours have to run at the same time
-    //  on one XCD, or every line is fetched once per tile that shares it: 4-column tiles 1.5-1.6x slower in runs)
+    //  on one XCD, or every line is fetched once per tile that shares it: 2- and 4-column tiles 1.2-1.6x slower in runs)
     static constexpr bool HERM_RUNS = HERM_ && !XCD_CHUNK;
     static constexpr int HERM_OFF = DATA_ELEMS + TWL_TOTAL + CS_ELEMS;
     static constexpr int HERM_ELEMS = HERM_RUNS ? N_ : 0;

@@ -25,7 +25,7 @@ def main():
         out = torch.empty(shape + (2,), device="cuda:0")
         res = {}
         for mode in ("0", "h", "1", "0", "h", "1"):  # off / Hermitian last pass alone / with the half-store pass before it
-            os.environ["MIFFT_HERM"] = "0" if mode == "0" else "1"
+            os.environ["MIFFT_HERM"] = "0" if mode == "0" else os.environ.get("PROBE_HERM_ON", "1")  # (2: beyond the policy)
             os.environ["MIFFT_HS"] = "1" if mode == "1" else "0"
             with mf.DeviceContext(0) as ctx:
                 plan = mf.plan_fft(torch.float32, torch.float32, x.shape, out.shape, ctx=ctx)
