@@ -507,6 +507,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
     for (const FastEntry& e : kFastTable)  // hand-tuned entries win
         if (try_entry(e)) return true;
     hand_table = false;
+    if (config().skip_gen_table) return false;  // (lab switch)
     int ngen = 0;
     const FastEntry* gen;
     if (plan.out_dtype == MIFFT_F64)

@@ -65,6 +65,9 @@ struct Config {
     int jit_nt = -1;                 // -1 default policy, 0 no non-temporal runtime-specialised kernels, 1 streaming hints too
     bool jit_image = false;          // L2-resident image kernel (negative result, DESIGN_EXPERIMENTS.md)
     bool dpp = false;                // wave-shuffle radix-3 kernel for N = 93 (negative result)
+    std::string jit_cols_cfg;        // MIFFT_JIT_COLS_CFG="10x12x16:8:512": radices : tile : threads of the runtime-specialised column
+                                     // tiles of that length (tools/cols_cfg_sweep.py)
+    bool skip_gen_table = false;     // MIFFT_SKIP_GEN_TABLE=1: generated table entries ignored (runtime-specialised kernels instead; A/B)
     bool half_store = true;          // half-store kernel in front of a Hermitian last pass (MIFFT_HS=0: A/B baseline)
     int herm = 1;                    // Hermitian twins for the last pass of real-input N-D plans: 1 = where herm_pays() says so,
                                      // MIFFT_HERM=0 never (A/B baseline), MIFFT_HERM=2 wherever a twin exists (small test shapes)
@@ -96,6 +99,8 @@ inline Config load_config() {
     if (const char* v = env("MIFFT_JIT_NT")) c.jit_nt = atoi(v);
     if (const char* v = env("MIFFT_JIT_IMAGE")) c.jit_image = v[0] == '1';
     if (const char* v = env("MIFFT_DPP")) c.dpp = v[0] == '1';
+    if (const char* v = env("MIFFT_JIT_COLS_CFG")) c.jit_cols_cfg = v;
+    if (const char* v = env("MIFFT_SKIP_GEN_TABLE")) c.skip_gen_table = v[0] == '1';
     if (const char* v = env("MIFFT_HS")) c.half_store = v[0] != '0';
     if (const char* v = env("MIFFT_HERM")) c.herm = v[0] == '0' ? 0 : v[0] == '2' ? 2 : 1;
     if (const char* v = env("MIFFT_GRID_PER_CU")) c.grid_per_cu = atoi(v);
