@@ -1,5 +1,5 @@
 """Randomised end-to-end check of the GPU path against fp64 pocketfft (GPU box):
-    python tools/fuzz_gpu.py [cases] [seed]
+    python tools/fuzz_gpu.py [cases] [seed] [big]
 Random ranks 1-5, arbitrary lengths (so every kernel family is hit: tables, runtime-specialised rows / column tiles /
 planes, literal stages, four-step), fp32 / fp64, real / complex / uint8 / int32 input, forward / inverse, ragged batches.
 Prints every failure and a per-family count; exit status 1 on any failure."""
@@ -11,13 +11,23 @@ import hackathon_fft_amd as mf
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+# "big": 2-D ... 4-D shapes of 2-30 M points, mostly real input -- large enough for the plan-time policy to take the Hermitian
+# last pass and the half-store pass in front of it (herm_pays, mifft_internal.h)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(seed)
 fam = collections.Counter()
 fails = 0
 t_start = time.time()
 for i in range(cases):
     nd = int(rng.choice([1, 1, 1, 2, 2, 2, 3, 3, 4, 5]))
-    if nd == 1:
+    if BIG:
+        nd = int(rng.choice([2, 2, 3, 3, 4]))
+        pool = [32, 48, 50, 64, 64, 80, 96, 100, 120, 128, 128, 160, 200, 243, 256, 256, 320, 360, 384, 480, 500, 512, 640, 720, 1000, 1024, 1080]
+        cap = {2: 1100, 3: 260, 4: 70}[nd]
+        shape = tuple(int(rng.choice([v for v in pool if v <= cap])) for _ in range(nd))
+        pts = int(np.prod(shape))
+        batch = int(max(1, min(400, rng.integers(2_000_000, 30_000_000) // pts)))
+    elif nd == 1:
         n = int(rng.choice([rng.integers(2, 700), rng.integers(2, 5000), 2 ** int(rng.integers(1, 15)), rng.integers(16385, 70000)]))
         shape = (n,)
         batch = int(rng.integers(1, max(2, min(300, 200000 // n))))
@@ -32,6 +42,8 @@ for i in range(cases):
         batch = int(rng.integers(1, 3))
     out_dt = np.float32 if rng.random() < 0.65 else np.float64
     kind = rng.choice(["c", "c", "r", "u8", "i32", "mixed"])
+    if BIG:
+        kind = rng.choice(["r", "r", "r", "u8", "i32", "c"])
     inverse = bool(rng.random() < 0.3)
     comps = 2
     if kind == "c":
@@ -68,6 +80,10 @@ for i in range(cases):
     if "generic" in names and os.environ.get("FUZZ_SHOW_GENERIC"):
         print(f"generic: {shape} batch {batch} {kind} {out_dt.__name__} {names}")
     for nm in set(names):
+        if nm.endswith(("_h", "_h_jit")):
+            fam["hermitian"] += 1
+        if "_hs" in nm:
+            fam["half-store"] += 1
         key = "generic" if nm == "generic" else "jit" if nm.endswith("_jit") else "transpose" if nm == "transpose" else "table"
         if "_ts" in nm:
             key = "fourstep-" + key
