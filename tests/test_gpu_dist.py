@@ -127,3 +127,31 @@ def test_slab_plans_choose_their_kernels_for_the_whole_batch(shape, world):
         mf.fft(os_, xs, ctx, plan=slab)
         ctx.synchronize()
         assert torch.equal(os_, out[first:first + count]), (shape, first, count)
+
+
+@pytest.mark.parametrize("shape,world", [((10, 128, 128, 128), 8), ((100, 640, 480), 4), ((7, 256, 256, 256), 3)])
+def test_slab_plans_of_real_input_keep_the_hermitian_schedule(shape, world):
+    """Real input: the whole batch takes a Hermitian last pass behind a half-store pass (herm_pays counts the rounds of the
+    persistent grid for the WHOLE batch); a slab plan must take the same kernels -- a slab by itself would often be too small
+    for them -- and equal the same rows bit for bit."""
+    import torch
+    import hackathon_fft_amd as mf
+    from hackathon_fft_amd.dist import all_shard_bounds
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(shape + (1,), generator=g, device=dev)
+    out_shape = shape + (2,)
+    ctx = mf.DeviceContext(0)
+    whole = mf.plan_fft(torch.float32, torch.float32, x.shape, out_shape, ctx=ctx)
+    out = torch.empty(out_shape, device=dev)
+    mf.fft(out, x, ctx, plan=whole)
+    names = [whole.kernel_name(d) for d in range(len(shape) - 1)]
+    assert names[0].endswith(("_h", "_h_jit")) and "_hs" in names[1], names
+    for first, count in all_shard_bounds(shape[0], world):
+        xs = x[first:first + count].contiguous()
+        slab = mf.plan_fft(torch.float32, torch.float32, xs.shape, (count,) + out_shape[1:], ctx=ctx, whole_batch=shape[0])
+        assert [slab.kernel_name(d) for d in range(len(shape) - 1)] == names
+        os_ = torch.full((count,) + out_shape[1:], float("nan"), device=dev)
+        mf.fft(os_, xs, ctx, plan=slab)
+        ctx.synchronize()
+        assert torch.equal(os_, out[first:first + count]), (shape, first, count)
