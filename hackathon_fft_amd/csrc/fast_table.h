@@ -29,7 +29,14 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
             tp.herm_d0 = pass.herm_d0;
             tp.herm_d1 = pass.herm_d1;
             tp.herm_d2 = pass.herm_d2;
-            tp.tiles_per_outer = (herm_prefix(pass.herm_d0, pass.herm_d1, pass.herm_d2) + C::TILE - 1) / C::TILE;
+            tp.herm_dj = pass.herm_dj;
+            tp.herm_js = pass.herm_js;
+            tp.herm_L = pass.herm_L;
+            tp.herm_H = pass.herm_H;
+            tp.herm_tpr = (pass.herm_H + C::TILE - 1) / C::TILE;
+            tp.tiles_per_outer = herm_tiles_per_outer(pass, C::TILE);
+        } else if (pass.col_prefix > 0) {  // (middle pass of a half-spectrum schedule: only the columns that were stored)
+            tp.tiles_per_outer = (pass.col_prefix + C::TILE - 1) / C::TILE;
         }
         tp.n_tiles = count * pass.outer * tp.tiles_per_outer;
     } else {

@@ -96,6 +96,15 @@ static const FastEntry kFastTable[] = {
     MIFFT_CFG_HS_X(true, 0, -1, false, "rows480_10x6x8_r", float, MIFFT_F32, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_HS_X(true, 1, 2, false, "rows640_10x8x8_r_ntl", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
     MIFFT_CFG_HS_X(true, 0, -1, false, "rows640_10x8x8_r", float, MIFFT_F32, 640, 3, 10, 8, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+    // ... power-of-two rows: the streaming twin (stream_pref 1) and the plain kernel
+    MIFFT_CFG_HS_X(true, 3, 1, false, "rows1024_16x8x8_r_nt", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+    MIFFT_CFG_HS_X(true, 0, -1, false, "rows1024_16x8x8_r", float, MIFFT_F32, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+    MIFFT_CFG_HS_X(true, 3, 1, false, "rows512_8x8x8_r_nt", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_HS_X(true, 0, -1, false, "rows512_8x8x8_r", float, MIFFT_F32, 512, 3, 8, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_HS_X(true, 3, 1, false, "rows256_8x8x4_r_nt", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_HS_X(true, 0, -1, false, "rows256_8x8x4_r", float, MIFFT_F32, 256, 3, 8, 8, 4, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_HS_X(true, 3, 1, false, "rows2048_16x16x8_r_nt", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
+    MIFFT_CFG_HS_X(true, 0, -1, false, "rows2048_16x16x8_r", float, MIFFT_F32, 2048, 3, 16, 16, 8, 1, 2, 256, false, true, true, TW_LDS, 2, false),
     MIFFT_CFG_HS("cols128_16x8_w32", float, MIFFT_F32, 128, 2, 16, 8, 1, 1, 32, 512, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG_HS("cols128_8x4x4", float, MIFFT_F32, 128, 3, 8, 4, 4, 1, 16, 256, true, true, true, TW_LDS, 4, false),
     MIFFT_CFG_HS("cols64_8x8_w64", float, MIFFT_F32, 64, 2, 8, 8, 1, 1, 64, 512, true, true, true, TW_LDS, 2, false),
@@ -488,6 +497,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
             return false;
         if (e.stream_pref == 4 && !(plan.ndim == 1 && total_bytes > config().nts_small_min_bytes)) return false;
         if (cols && e.tile > 16 && pass.inner % e.tile != 0) return false;  // wide tiles: whole tiles only
+        if (cols && e.tile > 16 && pass.col_prefix % e.tile != 0) return false;  // (also of a transformed column prefix)
         // (a strided dimension with fewer columns than one tile still runs here: the ragged tile clamps its loads and
         //  masks its stores; the literal-stage alternative is an order of magnitude slower)
         pass.kernel_name = e.name;
@@ -500,6 +510,7 @@ bool select_fast(const Plan& plan, DimPass& pass) {
         pass.wg_per_cu = grid_per_cu_of(e.name);
         pass.hs = e.hs;
         pass.regime_twin = e.stream_pref > 0;
+        pass.prefix_ok = e.cols && !e.tstore && !e.herm;
         pass.herm_d0 = pass.herm_d1 = pass.herm_d2 = 0;
         if (e.herm) herm_set_dims(plan, pass);  // trailing dimensions of the column space
         return true;

@@ -339,6 +339,27 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
         herm_known = ok ? 1 : 0;
         return ok;
     };
+    // Half-spectrum schedule of a real-input plan with exactly one pass between the first and the last (rows / columns /
+    // columns of a 3-D plan, plane / columns / columns of a 4-D one): the FIRST pass stores only the lower half of the dimension
+    // it transforms last (dims[2]), the middle pass transforms only those columns, the Hermitian last pass halves that same
+    // dimension (Plan::herm_axis = 2) -- every pass but the last moves half the tensor.  Falls back to the schedule with the
+    // half store on the pass before the last (herm_axis = 1) when a kernel is missing.
+    bool allow_first_axis = cfg.herm_first_axis, first_axis = false;
+    auto try_first_axis = [&](DimPass& t, bool found) -> bool {  // t: the first pass with a half-store kernel selected
+        if (!found) return false;
+        p.herm_axis = 2;
+        p.hs_selected = true;
+        herm_known = -1;
+        if (last_pass_will_be_hermitian()) return true;
+        p.herm_axis = 1;
+        p.hs_selected = false;
+        herm_known = -1;  // (asked again, for the other schedule, when the pass over dimension 1 is selected)
+        if (t.d_aux) (void)hipFree(t.d_aux);
+        if (t.d_aux2) (void)hipFree(t.d_aux2);
+        t.d_aux = t.d_aux2 = nullptr;
+        return false;
+    };
+build_passes:
     for (int i = ndim - 1; i >= 0; --i) {
         DimPass ps;
         ps.dim_index = i;
@@ -364,7 +385,16 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
                 for (int k = 0; k < i - 1; ++k) pl.outer *= dims[k];
                 std::string whyp;
                 bool fused = false;
-                if (i - 1 == 1 && herm_possible()) {  // the plane's column side is dimension 1: half store
+                if (allow_first_axis && ndim == 4 && herm_possible()) {  // plane / columns / columns: halve the plane's column side
+                    DimPass t = pl;
+                    t.want_half = true;
+                    t.store_lim = (int)(dims[2] / 2);
+                    if (try_first_axis(t, select_fast_plane(p, t) || select_jit_plane(p, t, whyp))) {
+                        pl = t;
+                        fused = first_axis = true;
+                    }
+                }
+                if (!fused && i - 1 == 1 && herm_possible()) {  // the plane's column side is dimension 1: half store
                     DimPass t = pl;
                     t.want_half = true;
                     t.store_lim = (int)(dims[1] / 2);
@@ -383,11 +413,32 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
                     --i;  // dimension i-1 is covered by this pass
                 }
             }
+            // rows / columns / columns of a real-input 3-D plan: the row pass stores the lower half of every row
+            if (!ok && allow_first_axis && ndim == 3 && i == 2 && herm_possible()) {
+                DimPass t = ps;
+                t.want_half = true;
+                t.store_lim = (int)(dims[2] / 2);
+                bool found = select_fast(p, t);
+                if (!found && ps.N <= 4096) {
+                    DimPass u = ps;
+                    const bool tuned = select_fast(p, u) && u.regime_twin;
+                    std::string whyh;
+                    found = !tuned && select_jit(p, t, whyh);
+                }
+                if (try_first_axis(t, found)) {
+                    ps = t;
+                    ok = first_axis = true;
+                }
+            }
+            if (first_axis && i == 1) {  // the middle pass: only the columns the first pass stored
+                ps.col_prefix = dims[2] / 2 + 1;
+                for (int k = 3; k < ndim; ++k) ps.col_prefix *= dims[k];
+            }
             // the pass over dimension 1 of a plan whose last pass will be a Hermitian twin: a half-store kernel, tuned or
             // runtime specialised, before anything else
             // (a kernel tuned for a size regime -- a non-temporal twin -- is not traded for a runtime-specialised one: 64 x 1024^2
             //  0.372 -> 0.422 ms with `rows1024_16x8x8_hs_r_jit` in place of `rows1024_16x8x8_r_nt`)
-            if (!ok && i == 1 && herm_possible()) {
+            if (!ok && i == 1 && !first_axis && herm_possible()) {
                 DimPass t = ps;
                 t.want_half = true;
                 t.store_lim = (int)(dims[1] / 2);
@@ -528,6 +579,21 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
             free_plan_device(p);
             delete h;
             return hip_error(e, "twiddle table upload");
+        }
+    }
+    if (first_axis) {  // the half-spectrum schedule needs all three of its kernels; else build the plan again without it
+        const bool good = p.passes.size() == 3 && p.passes[0].hs && p.passes[1].prefix_ok && p.passes[2].herm_d2 > 0 &&
+                          p.passes[2].herm_dj == (int)dims[2];
+        if (!good) {
+            free_plan_device(p);
+            p.passes.clear();
+            p.scratch_bytes = 0;
+            p.alloc_failed = false;
+            p.herm_axis = 1;
+            p.hs_selected = false;
+            herm_known = -1;
+            allow_first_axis = first_axis = false;
+            goto build_passes;
         }
     }
     {   // a half-store pass is only right in front of a Hermitian last pass (both selections are deterministic; this is the

@@ -80,6 +80,12 @@ struct DimPass {
     bool want_herm = false;
     bool herm_only = false;  // (select_fast: accept only Hermitian twins -- the scheduler tries those first)
     int herm_d0 = 0, herm_d1 = 0, herm_d2 = 0;
+    // ... and the half axis of the column space (TileParams::herm_dj ...): size, stride, row length, covered prefix of a row
+    int herm_dj = 0, herm_js = 0, herm_L = 0, herm_H = 0;
+    // an ordinary column pass between a half-store first pass and the Hermitian last pass transforms only the first
+    // col_prefix columns of its column space (0 = all): the others were not stored and are not read
+    long long col_prefix = 0;
+    bool prefix_ok = false;  // the selected kernel honours col_prefix (the column tiles do, special routes do not)
     // the pass BEFORE such a last pass (it transforms dims[1], the dimension the Hermitian pass halves; a plane: its column
     // side) may store only the results 0 .. store_lim = dims[1] / 2 (TileCfg::HS): want_half asks the families for such a
     // kernel ONLY, `hs` says the selected kernel is one
@@ -117,6 +123,11 @@ struct Plan {
     // plan creation only: the pass over dimension 1 has been given a half-store kernel (TileCfg::HS), which widens the cases
     // in which a Hermitian last pass pays (herm_pays)
     bool hs_selected = false;
+    // plan creation only: the dimension the Hermitian last pass halves (index into dims).  1: the dimension of the pass right
+    // before it, which then stores only half of its results; 2: the dimension the FIRST pass transforms -- the rows of a
+    // three-pass 3-D plan, the column side of the plane of a 4-D one -- with a half-store first pass and a middle pass over the
+    // lower half of its columns: every pass but the last then moves half the tensor.
+    int herm_axis = 1;
     size_t in_elem_bytes() const;
     size_t out_elem_bytes() const;  // bytes of one complex output element
 };
@@ -124,15 +135,21 @@ struct Plan {
 // Hermitian twins: the trailing dimensions of the column space of the last pass (dims[1..ndim-1], at most three; absent
 // leading ones are 1), and the flat prefix of columns that are not beyond their own mirror image
 inline void herm_set_dims(const Plan& plan, DimPass& pass) {
-    const int n = plan.ndim;
+    const int n = plan.ndim, a = plan.herm_axis;
     pass.herm_d2 = (int)plan.dims[n - 1];
     pass.herm_d1 = n >= 3 ? (int)plan.dims[n - 2] : 1;
     pass.herm_d0 = n >= 4 ? (int)plan.dims[n - 3] : 1;
+    long long js = 1;
+    for (int k = a + 1; k < n; ++k) js *= plan.dims[k];
+    pass.herm_dj = (int)plan.dims[a];
+    pass.herm_js = (int)js;
+    pass.herm_L = (int)(plan.dims[a] * js);
+    pass.herm_H = (int)((plan.dims[a] / 2 + 1) * js);
 }
-inline long long herm_prefix(int d0, int d1, int d2) {
-    if (d0 > 1) return (long long)(d0 / 2 + 1) * d1 * d2;
-    if (d1 > 1) return (long long)(d1 / 2 + 1) * d2;
-    return d2 / 2 + 1;
+// tiles of `tile` columns that cover the transformed part of one image's column space
+inline long long herm_tiles_per_outer(const DimPass& pass, int tile) {
+    const long long rows = pass.inner / pass.herm_L, tpr = (pass.herm_H + tile - 1) / tile;
+    return rows * tpr;
 }
 
 // Does a Hermitian twin (TileCfg::HERM) with `tile` columns per tile pay for this pass?  Measured with tools/herm_probe.py
@@ -165,7 +182,7 @@ inline bool herm_pays(const Plan& plan, const DimPass& pass, int tile, size_t ld
     const long long grid = (long long)plan.num_cus * per_cu;
     const long long images = (long long)plan.size_batch() * pass.outer;
     const long long full = images * ((pass.inner + tile - 1) / tile);
-    const long long half = images * ((herm_prefix(dims.herm_d0, dims.herm_d1, dims.herm_d2) + tile - 1) / tile);
+    const long long half = images * herm_tiles_per_outer(dims, tile);
     const long long rounds_full = (full + grid - 1) / grid, rounds_half = (half + grid - 1) / grid;
     return (double)rounds_half <= (pass.N >= 128 ? 0.75 : 0.70) * (double)rounds_full;
 }

@@ -124,9 +124,13 @@ struct TileParams {
     // FS1 configurations: `inner` is the LOAD row stride N2 * fs_inner; rows are stored at stride fs_inner
     long long fs_inner;
     long long fs_n2;
-    // HERM configurations (last pass of a REAL-input N-D plan, in place): the trailing dimensions (d1, d2) of the column
-    // index space (d1 = 1 for a 2-D plan); tiles_per_outer covers only the flat prefix [0, (d1/2 + 1) * d2) of the columns
-    int herm_d0, herm_d1, herm_d2;  // HERM: the trailing dimensions of the column space (leading ones 1 when absent)
+    // HERM configurations (last pass of a REAL-input N-D plan, in place): herm_d0 x herm_d1 x herm_d2 are the trailing
+    // dimensions, i.e. the column space (leading ones 1 when absent).  One of them is the HALF AXIS (size herm_dj, stride
+    // herm_js columns): the pass transforms the columns whose index along it is at most herm_dj / 2 and owns those below the
+    // middle.  The column space is herm_rows rows of herm_L = herm_dj * herm_js columns; the first herm_H = (herm_dj / 2 + 1)
+    // * herm_js columns of every row are covered by herm_tpr tiles, tiles_per_outer = rows * herm_tpr.
+    int herm_d0, herm_d1, herm_d2;
+    int herm_dj, herm_js, herm_L, herm_H, herm_tpr;
     // HS configurations (the pass BEFORE a HERM last pass; a plane: its column side): results with an output index above
     // store_lim are not stored -- the last pass reads only the half of that dimension up to its middle and writes the rest
     int store_lim;
@@ -663,6 +667,32 @@ MIFFT_DEV int herm_mirror(const TileParams& p, int cf) {
     return ((kz ? p.herm_d0 - kz : 0) * d1 + (ky ? d1 - ky : 0)) * d2 + (kx ? d2 - kx : 0);
 }
 
+// HERM: does this pass compute column cf itself (`own`), and has the column a mirror image other than itself (`twice`)?
+// Below the middle of the half axis: yes; beyond it: no (the mirror image's tile stores it); on a self-mirrored index of the
+// half axis the flat order of the pair decides.
+MIFFT_DEV void herm_owner(const TileParams& p, int cf, int mf, bool& own, bool& twice) {
+    const int in_row = cf % p.herm_L, kj = in_row / p.herm_js;
+    own = (kj == 0 || 2 * kj == p.herm_dj) ? cf <= mf : 2 * kj < p.herm_dj;
+    twice = own && cf != mf;
+}
+MIFFT_DEV bool herm_twice(const TileParams& p, int cf) {
+    bool own, twice;
+    herm_owner(p, cf, herm_mirror(p, cf), own, twice);
+    return twice;
+}
+// HERM: tile t -> (outer index, row of the column space, tile inside the covered part of the row)
+template <class C>
+MIFFT_DEV void tile_geom_herm(const TileParams& p, long long t, long long& base, int& nv, int& col0, int& in_row) {
+    const long long o = t / p.tiles_per_outer;
+    const int in_image = (int)(t - o * p.tiles_per_outer);
+    const int r = in_image / p.herm_tpr;
+    in_row = in_image - r * p.herm_tpr;
+    col0 = r * p.herm_L + in_row * C::TILE;
+    const int left = p.herm_H - in_row * C::TILE;
+    nv = left < C::TILE ? left : C::TILE;
+    base = o * (long long)C::N * p.inner + col0;
+}
+
 // registers -> butterflies -> Stockham scatter (LDS, or HBM for the last pass)
 template <class C, int I>
 MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds, cpx<typename C::T> (*v)[C::R(I)],
@@ -721,8 +751,10 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
                 const int col0 = fs_row & 0x3fffffff;
                 const bool carry_in = (fs_row >> 30) & 1, carry_out = ((unsigned)fs_row >> 31) != 0;
                 const int cf = col0 + c, mf = herm_mirror(p, cf);
-                const bool alive = c < nv && cf <= mf;  // (columns beyond their mirror belong to the mirror's tile)
-                const bool first = c == 0, twice = alive && cf < mf;
+                bool own, has_mirror;
+                herm_owner(p, cf, mf, own, has_mirror);
+                const bool alive = c < nv && own;  // (the other columns belong to their mirror image's tile)
+                const bool first = c == 0, twice = c < nv && has_mirror;
                 const bool keep = first && twice && carry_out;              // first column: left in LDS for the next tile,
                 const bool lone = first && twice && !carry_out && carry_in;  // or stored by itself at the end of a run
                 const bool mirrored = first ? carry_in || (twice && !carry_out) : twice;           // the mirrored store ...
@@ -1149,7 +1181,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
         if (t < t_end) {
             long long base;
             int nv;
-            tile_geom<C>(p, tile_at(t), base, nv);
+            if constexpr (C::HERM) {
+                int col0, in_row;
+                tile_geom_herm<C>(p, tile_at(t), base, nv, col0, in_row);
+            } else {
+                tile_geom<C>(p, tile_at(t), base, nv);
+            }
             load_pass0<C>(p, pre, base, nv, tid0);
         }
     }
@@ -1170,24 +1207,22 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
         int fs_row = 0;
         if constexpr (C::FS1) {
             tile_geom_fs1<C>(p, tt, base, obase, nv, fs_row);
+        } else if constexpr (C::HERM) {  // image base and first column of the tile, for the mirrored stores
+            int in_row;
+            tile_geom_herm<C>(p, tt, base, nv, fs_row, in_row);
+            obase = base - fs_row;
+            // tile tt hands its first column to tile tt - 1 when that is the next of this run, covers the columns right below
+            // it, and the column has a mirror image to be stored at all; the same test one tile up says whether tile tt + 1
+            // did so (not across the start of a row of the last dimension: that column's mirror image is the FIRST element of
+            // a row, next to nothing the neighbouring tile stores)
+            if constexpr (C::HERM_RUNS) {
+                const int nxt = fs_row + C::TILE;
+                const bool out = t + 1 < t_end && fs_row % p.herm_d2 != 0 && herm_twice(p, fs_row);
+                const bool in = t > run_begin && in_row + 1 < p.herm_tpr && nxt % p.herm_d2 != 0 && herm_twice(p, nxt);
+                fs_row |= (in ? 1 << 30 : 0) | (out ? (int)(1u << 31) : 0);
+            }
         } else {
             tile_geom<C>(p, tt, base, nv);
-            if constexpr (C::HERM) {  // image base and first column of the tile, for the mirrored stores
-                const long long in_image = tt % p.tiles_per_outer;
-                fs_row = (int)(in_image * C::TILE);
-                obase = base - fs_row;
-                // tile tt hands its first column to tile tt - 1 when that is the next of this run, lies in the same image,
-                // and the column has a mirror image at all; the same test one tile up says whether tile tt + 1 did so
-                // (not across the start of a row of the trailing dimension: that column's mirror image is the FIRST element
-                //  of a row, next to nothing the neighbouring tile stores)
-                if constexpr (C::HERM_RUNS) {
-                    const int nxt = fs_row + C::TILE;
-                    const bool out = t + 1 < t_end && fs_row % p.herm_d2 != 0 && fs_row < herm_mirror(p, fs_row);
-                    const bool in = t > run_begin && in_image + 1 != p.tiles_per_outer && nxt % p.herm_d2 != 0 &&
-                                    nxt < herm_mirror(p, nxt);
-                    fs_row |= (in ? 1 << 30 : 0) | (out ? (int)(1u << 31) : 0);
-                }
-            }
         }
         V cur[C::PREFETCH ? C::IPT(0) : 1][C::R(0)];
         // seams between passes where a slice of the next tile's loads can go: 2 NP - 3 of them, plus the top
@@ -1202,7 +1237,14 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
             for (int k = 0; k < C::IPT(0); ++k)
 #pragma unroll
                 for (int j = 0; j < C::R(0); ++j) cur[k][j] = pre[k][j];
-            if (tn < t_end) tile_geom<C>(p, tile_at(tn), nbase, nnv);
+            if (tn < t_end) {
+                if constexpr (C::HERM) {
+                    int col0, in_row;
+                    tile_geom_herm<C>(p, tile_at(tn), nbase, nnv, col0, in_row);
+                } else {
+                    tile_geom<C>(p, tile_at(tn), nbase, nnv);
+                }
+            }
             if constexpr (SLICES == 1) {
                 if (tn < t_end) load_pass0<C>(p, pre, nbase, nnv, tid);  // all of the next tile's HBM reads at once
             } else {

@@ -146,7 +146,7 @@ def test_slab_plans_of_real_input_keep_the_hermitian_schedule(shape, world):
     out = torch.empty(out_shape, device=dev)
     mf.fft(out, x, ctx, plan=whole)
     names = [whole.kernel_name(d) for d in range(len(shape) - 1)]
-    assert names[0].endswith(("_h", "_h_jit")) and "_hs" in names[1], names
+    assert names[0].endswith(("_h", "_h_jit")) and any("_hs" in n for n in names[1:]), names
     for first, count in all_shard_bounds(shape[0], world):
         xs = x[first:first + count].contiguous()
         slab = mf.plan_fft(torch.float32, torch.float32, xs.shape, (count,) + out_shape[1:], ctx=ctx, whole_batch=shape[0])

@@ -147,7 +147,11 @@ def test_dpp_radix3_rows(shape, inverse, monkeypatch):
                                          ((1, 1920, 200), np.float32),    # 8-column tiles: no carried column
                                          ((2, 360, 280), np.float64), ((2, 20, 24, 28), np.float64),
                                          ((1, 64, 16, 8, 64), np.float32), ((2, 12, 5, 6, 14), np.float32),  # three trailing dimensions
-                                         ((400, 640, 48), np.float32)])   # runs of several tiles per workgroup across images
+                                         ((400, 640, 48), np.float32),    # runs of several tiles per workgroup across images
+                                         # three passes (no plane fits LDS): half-store ROW pass, middle pass over half the columns,
+                                         # last pass halving the last dimension
+                                         ((1, 12, 200, 180), np.float32), ((2, 10, 130, 150), np.float32), ((1, 8, 120, 100), np.float64),
+                                         ((1, 16, 256, 256), np.float32), ((3, 6, 96, 250), np.float32)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_hermitian_twins_forced_on_small_shapes(shape, dtype, inverse, monkeypatch):
     """MIFFT_HERM=2 takes the Hermitian twin of the last pass wherever one exists, also where the plan-time policy of the

@@ -732,6 +732,13 @@ int main(int argc, char** argv) {
         VR("r 16x8x8 t4 256 lds w4 pf nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 256, false, true, true, TW_LDS, 4, true),
         VR("r 16x8x8 t8 512 lds w2 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 8, 512, false, true, true, TW_LDS, 2, false),
         VR("r 4x4x8x8 t4 512 lds w2 flat nt3", 3, float, 1024, 4, 4, 4, 8, 8, 4, 512, false, false, true, TW_LDS, 2, false),
+        // round 3 (real input no longer conjugates its loads): two passes, other splits
+        VR("r 32x32 t4 128 lds w2 nt3", 3, float, 1024, 2, 32, 32, 1, 1, 4, 128, false, true, true, TW_LDS, 2, false),
+        VR("r 32x32 t8 256 lds w4 nt3", 3, float, 1024, 2, 32, 32, 1, 1, 8, 256, false, true, true, TW_LDS, 4, false),
+        VR("r 16x16x4 t4 256 lds w4 nt3", 3, float, 1024, 3, 16, 16, 4, 1, 4, 256, false, true, true, TW_LDS, 4, false),
+        VR("r 16x8x8 t2 128 lds w2 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 2, 128, false, true, true, TW_LDS, 2, false),
+        VR("r 16x8x8 t4 512 lds w4 nt3", 3, float, 1024, 3, 16, 8, 8, 1, 4, 512, false, true, true, TW_LDS, 4, false),
+        VR("r 8x16x8 t4 256 lds w4 nt3", 3, float, 1024, 3, 8, 16, 8, 1, 4, 256, false, true, true, TW_LDS, 4, false),
     };
 #elif GROUP == 25  // ---- 8K frame, other orientation: 7680 rows of 4320 ----
     const long long batch = 7680, outer = 1, inner = 1;
