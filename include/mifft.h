@@ -34,7 +34,7 @@
  * Nothing else is configurable in libmifft.so: every size threshold of the plan-time policy is a
  * constant derived from the 256-MiB Infinity Cache (kInfinityCacheBytes).  The measurement switches the
  * scripts under tools/ use (MIFFT_ND_CACHE, MIFFT_NTS_*, MIFFT_FOURSTEP_*, MIFFT_FS_*, MIFFT_ROW2D,
- * MIFFT_JIT_NT, MIFFT_JIT_IMAGE, MIFFT_DPP, MIFFT_HERM, MIFFT_HS, MIFFT_GRID_PER_CU) and the fault injection of the tests
+ * MIFFT_JIT_NT, MIFFT_JIT_IMAGE, MIFFT_DPP, MIFFT_HERM*, MIFFT_HS, MIFFT_GRID_PER_CU) and the fault injection of the tests
  * (MIFFT_TEST_FAIL_SCRATCH_ALLOC) exist only in the LAB build, libmifft_lab.so
  * (-DMIFFT_EXPERIMENTAL -DMIFFT_TESTING, same ABI), together with the experimental kernels that stayed
  * negative results; the host package loads it only when MIFFT_LIBRARY points at it.
