@@ -234,6 +234,22 @@ def test_batch_range_and_untouched_rows():
     assert np.isnan(empty).all()
 
 
+@pytest.mark.parametrize("shape", [(25, 640, 480), (12, 128, 128, 128), (3, 256, 256, 256)])
+def test_batch_range_of_a_real_input_plan_with_hermitian_passes(shape):
+    """mifft_exec_batch(first, count) on plans whose passes skip / mirror halves of the tensor (`_hs`, `_h`): the rows inside
+    the range equal the whole-batch result bit for bit, the rows outside are not touched -- the mirrored stores of the last
+    pass stay inside their own image."""
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape + (1,)).astype(np.float32)
+    full, plan = gpu_fft(x, out_dtype=np.float32)
+    names = [plan.kernel_name(d) for d in range(len(shape) - 1)]
+    assert names[0].endswith(("_h", "_h_jit")) and any("_hs" in n for n in names[1:]), names
+    first, count = 1, max(1, shape[0] // 2)
+    part, _ = gpu_fft(x, out_dtype=np.float32, first=first, count=count)
+    assert np.isnan(part[:first]).all() and np.isnan(part[first + count:]).all()
+    assert np.array_equal(part[first:first + count], full[first:first + count])
+
+
 @pytest.mark.parametrize("shape", [(10, 1024), (37, 93), (21, 128), (19, 480), (3, 40, 64)])
 def test_results_do_not_depend_on_the_tile_slot(shape):
     """The same transform placed at every position of the batch gives bit-identical output (FMA placement is
