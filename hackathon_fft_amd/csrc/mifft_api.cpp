@@ -292,6 +292,11 @@ int mifft_plan_create_slab(mifft_plan** out_plan, int device, int in_dtype, int 
     auto upload_twiddles = [&](DimPass& ps) -> hipError_t {
         // (four-step rows inside LDS: the table of the row side, M / N1 points; the column side's goes to d_aux when it
         //  differs, the M-entry table to d_aux3)
+        if (ps.r2c) {  // packed real rows: the passes run N / 2 points; the unpacking needs W_N^k, forward
+            hipError_t e2 = upload_twiddle_table(out_dtype, ps.N / 2, inverse != 0, &ps.d_twiddle);
+            if (e2 == hipSuccess) e2 = upload_twiddle_table(out_dtype, ps.N, false, &ps.d_aux);
+            return e2;
+        }
         hipError_t e = upload_twiddle_table(out_dtype, ps.row2d_m > 0 ? ps.row2d_m / ps.N1 : ps.N, inverse != 0, &ps.d_twiddle);
         if (e == hipSuccess && ps.plane_needs_tw1) e = upload_twiddle_table(out_dtype, ps.N1, inverse != 0, &ps.d_aux);
         if (e == hipSuccess && ps.row2d_m > 0) e = upload_twiddle_table(out_dtype, ps.row2d_m, false, &ps.d_aux3);
@@ -418,7 +423,9 @@ build_passes:
                 DimPass t = ps;
                 t.want_half = true;
                 t.store_lim = (int)(dims[2] / 2);
-                bool found = select_fast(p, t);
+                std::string whyr;
+                bool found = cfg.r2c_rows && select_jit_r2c(p, t, whyr);
+                if (!found) found = select_fast(p, t);
                 if (!found && ps.N <= 4096) {
                     DimPass u = ps;
                     const bool tuned = select_fast(p, u) && u.regime_twin;
@@ -442,7 +449,9 @@ build_passes:
                 DimPass t = ps;
                 t.want_half = true;
                 t.store_lim = (int)(dims[1] / 2);
-                bool found = select_fast(p, t);
+                std::string whyr;
+                bool found = cfg.r2c_rows && ps.first && select_jit_r2c(p, t, whyr);  // (2-D plans: this is the row pass)
+                if (!found) found = select_fast(p, t);
                 if (!found && ps.N <= 4096) {
                     DimPass u = ps;
                     const bool tuned = select_fast(p, u) && u.regime_twin;

@@ -67,9 +67,13 @@ struct Config {
     bool dpp = false;                // wave-shuffle radix-3 kernel for N = 93 (negative result)
     std::string jit_cols_cfg;        // MIFFT_JIT_COLS_CFG="10x12x16:8:512": radices : tile : threads of the runtime-specialised column
                                      // tiles of that length (tools/cols_cfg_sweep.py)
+    std::string jit_rows_cfg;        // MIFFT_JIT_ROWS_CFG="16x15:16:256:1": radices : tile : threads : prefetch of the runtime-specialised
+                                     // ROW tiles of that length (packed real rows: of N / 2)
     bool skip_gen_table = false;     // MIFFT_SKIP_GEN_TABLE=1: generated table entries ignored (runtime-specialised kernels instead; A/B)
     bool herm_first_axis = true;     // half-spectrum schedule of three-pass real-input plans: halve the FIRST pass's dimension
                                      // (MIFFT_HERM_FIRST_AXIS=0: only the pass before the last stores half; A/B baseline)
+    bool r2c_rows = false;           // packed real rows (TileCfg::R2C) as the half-store first pass: MIFFT_R2C=1.  Measured: within
+                                     // -5 % / +5 % of the tuned half-store row kernels (DESIGN_EXPERIMENTS.md R3.8) -- not a default
     bool half_store = true;          // half-store kernel in front of a Hermitian last pass (MIFFT_HS=0: A/B baseline)
     int herm = 1;                    // Hermitian twins for the last pass of real-input N-D plans: 1 = where herm_pays() says so,
                                      // MIFFT_HERM=0 never (A/B baseline), MIFFT_HERM=2 wherever a twin exists (small test shapes)
@@ -102,8 +106,10 @@ inline Config load_config() {
     if (const char* v = env("MIFFT_JIT_IMAGE")) c.jit_image = v[0] == '1';
     if (const char* v = env("MIFFT_DPP")) c.dpp = v[0] == '1';
     if (const char* v = env("MIFFT_JIT_COLS_CFG")) c.jit_cols_cfg = v;
+    if (const char* v = env("MIFFT_JIT_ROWS_CFG")) c.jit_rows_cfg = v;
     if (const char* v = env("MIFFT_SKIP_GEN_TABLE")) c.skip_gen_table = v[0] == '1';
     if (const char* v = env("MIFFT_HERM_FIRST_AXIS")) c.herm_first_axis = v[0] != '0';
+    if (const char* v = env("MIFFT_R2C")) c.r2c_rows = v[0] == '1';
     if (const char* v = env("MIFFT_HS")) c.half_store = v[0] != '0';
     if (const char* v = env("MIFFT_HERM")) c.herm = v[0] == '0' ? 0 : v[0] == '2' ? 2 : 1;
     if (const char* v = env("MIFFT_GRID_PER_CU")) c.grid_per_cu = atoi(v);

@@ -90,6 +90,7 @@ struct DimPass {
     // side) may store only the results 0 .. store_lim = dims[1] / 2 (TileCfg::HS): want_half asks the families for such a
     // kernel ONLY, `hs` says the selected kernel is one
     bool want_half = false, hs = false;
+    bool r2c = false;  // packed real rows (TileCfg::R2C): the kernel runs N / 2 points; d_twiddle is that table, d_aux W_N^k
     int store_lim = 0;
     bool regime_twin = false;  // select_fast took an entry tuned for a size regime (non-temporal twin): not to be traded for
                                // a runtime-specialised half-store kernel
@@ -196,6 +197,9 @@ bool select_fast(const Plan& plan, DimPass& pass);
 bool select_dpp_rows(const Plan& plan, DimPass& pass);
 // the tile kernel specialised at plan time with hipRTC for a length without a table entry (kernels_jit.cpp)
 bool select_jit(const Plan& plan, DimPass& pass, std::string& why_not);
+// first pass over a REAL tensor whose last pass will be a Hermitian twin: rows read as N / 2 packed complex points, unpacked
+// into the half spectrum by the store loop (TileCfg::R2C); pass.want_half asks for it
+bool select_jit_r2c(const Plan& plan, DimPass& pass, std::string& why_not);
 // four-step helpers: the transposed + twiddled column pass (reads x: real / integer input allowed) and cheap
 // feasibility predicates for scoring factorisations without compiling
 bool select_jit_streaming_rows(const Plan& plan, DimPass& pass, std::string& why_not);  // LAB BUILD ONLY

@@ -134,6 +134,9 @@ struct TileParams {
     // HS configurations (the pass BEFORE a HERM last pass; a plane: its column side): results with an output index above
     // store_lim are not stored -- the last pass reads only the half of that dimension up to its middle and writes the rest
     int store_lim;
+    // R2C configurations: W_(2N)^k, k = 0 .. N (forward, whatever the plan's direction), and the row pitch of `out` (2 N)
+    const void* r2c_tw;
+    long long out_pitch;
 };
 
 MIFFT_DEV long long tile_id(const TileParams& p, long long t) { return p.reverse ? p.n_tiles - 1 - t : t; }
@@ -220,7 +223,7 @@ constexpr int rader_lds_elems(int R, int inst, int esz) {
 template <typename T_, int N_, int NP_, int R0_, int R1_, int R2_, int R3_, int TILE_, int THREADS_, bool COLS_,
           bool FIRST_DIRECT_, bool LAST_DIRECT_, int TWMODE_, int MINW_ = 1, bool PREFETCH_ = false, int ROWPAD_ = 0,
           bool IN_REAL_ = false, bool DMA_ = false, int NT_ = 0, bool TSTORE_ = false, typename IT_ = T_, bool WSUB_ = false,
-          bool FS1_ = false, int RADERM_ = 0, bool HERM_ = false, bool HS_ = false>
+          bool FS1_ = false, int RADERM_ = 0, bool HERM_ = false, bool HS_ = false, bool R2C_ = false>
 struct TileCfg {
     using T = T_;
     static constexpr int N = N_, NP = NP_, TILE = TILE_, THREADS = THREADS_, TWMODE = TWMODE_, MINW = MINW_;
@@ -322,6 +325,16 @@ struct TileCfg {
     // else and writes every other point itself.  Half the writes of that pass.
     static constexpr bool HS = HS_;
     static_assert(!HS_ || (!TSTORE_ && !FS1_ && !HERM_), "HS: a plain row / column tile or the column side of a plane");
+    // R2C: a row tile over a REAL tensor whose rows of 2 N points are read as N packed complex points z_n = x_2n + i x_2n+1
+    // (the row as it lies in memory), transformed by the ordinary passes, and unpacked into X[0 .. N] of the 2 N-point real
+    // transform by the store loop (the classic real-FFT split): half the butterflies and LDS traffic of a promoted (x, 0)
+    // row.  Only the half spectrum is produced, so it serves where a Hermitian last pass follows (it is a half-store kernel).
+    static constexpr bool R2C = R2C_;
+    static_assert(!R2C_ || (!COLS_ && !LAST_DIRECT_ && !IN_REAL_ && !TSTORE_ && !FS1_ && !HERM_ && !HS_ && !DMA_),
+                  "R2C: a row tile that leaves its last pass in LDS");
+    // inverse plans run conj(F(conj x)): complex input is conjugated as it is loaded (a real input is its own conjugate; the
+    // packed rows of R2C are unpacked first and conjugated as they are stored)
+    static constexpr bool CONJ_IN = !IN_REAL_ && !R2C_;
     static_assert(!FS1_ || (COLS_ && FIRST_DIRECT_ && LAST_DIRECT_ && !TSTORE_ && !WSUB_), "FS1: a direct column tile");
     static constexpr int CPITCH = TSTORE_ ? TILE_ + 1 : TILE_;
     static_assert(!TSTORE_ || (COLS_ && !LAST_DIRECT_ && FIRST_DIRECT_), "TSTORE: column tile, last pass left in LDS");
@@ -1068,7 +1081,7 @@ MIFFT_DEV void run_pass(const TileParams& p, cpx<typename C::T>* lds, const cpx<
             // inverse = conj(F(conj x)) / N.  A real input is its own conjugate: its imaginary parts stay the CONSTANT +0,
             // which lets the compiler fold the imaginary half of the first butterflies away (radix 31 on real input: 176 ->
             // VGPRs, no spill; a runtime -0 / +0 kept every one of them live).
-            if (p.inverse && !C::IN_REAL) {
+            if (p.inverse && C::CONJ_IN) {
 #pragma unroll
                 for (int k = 0; k < IPT; ++k)
 #pragma unroll
@@ -1277,7 +1290,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                     x = {gload_real<false>((const T*)p.in + gaddr<C>(p, base, cc, n)), (T)0};
                 else
                     x = gload<false>((const V*)p.in + gaddr<C>(p, base, cc, n));
-                if (p.inverse && !C::IN_REAL) x.y = -x.y;
+                if (p.inverse && C::CONJ_IN) x.y = -x.y;
                 lds[lds_index<C, -1>(c, n)] = x;
             }
             __syncthreads();
@@ -1295,7 +1308,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                         x.x = gload_real<(C::NT & 1) != 0>((const T*)p.in + base + f);
                     else
                         x = gload<(C::NT & 1) != 0>(gin + base + f);
-                    if (p.inverse && !C::IN_REAL) x.y = -x.y;
+                    if (p.inverse && C::CONJ_IN) x.y = -x.y;
                     lds[lds_index<C, -1>(c, n)] = x;
                 }
             }
@@ -1402,6 +1415,33 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void tile_kernel(const TilePar
                     }
                     gout[gaddr<C>(p, base, c, n)] = y;
                 }
+            }
+            __syncthreads();
+        } else if constexpr (C::R2C) {
+            // Z = F(z) of the packed row lies in LDS.  E[k] = (Z[k] + conj Z[N-k]) / 2 and O[k] = (Z[k] - conj Z[N-k]) / 2i are
+            // the transforms of the even and the odd samples; X[k] = E[k] + W^k O[k] and X[N-k] = conj(E[k] - W^k O[k]) with
+            // W = e^(-2 pi i / 2N); k = 0 gives X[0] and X[N].  One thread per pair (k, N - k), both runs of stores contiguous.
+            V* gout = (V*)p.out;
+            const V* w = (const V*)p.r2c_tw;
+            constexpr int PAIRS = C::N / 2 + 1;
+            const long long row0 = base / C::N;
+            for (int f = tid; f < nv * PAIRS; f += C::THREADS) {
+                const int c = f / PAIRS, k = f - c * PAIRS, m = k ? C::N - k : 0;
+                const V zk = lds[lds_index<C, C::NP - 1>(c, k)], zm = lds[lds_index<C, C::NP - 1>(c, m)];
+                const T ex = (T)0.5 * (zk.x + zm.x), ey = (T)0.5 * (zk.y - zm.y);
+                const T ox = (T)0.5 * (zk.y + zm.y), oy = (T)-0.5 * (zk.x - zm.x);
+                const V wk = w[k];
+                const T tx = wk.x * ox - wk.y * oy, ty = wk.x * oy + wk.y * ox;
+                V a = {ex + tx, ey + ty}, b = {ex - tx, ty - ey};
+                if (p.inverse) {  // the inverse of a real row: conj(X) / 2N
+                    a.x *= (T)p.scale;
+                    a.y *= -(T)p.scale;
+                    b.x *= (T)p.scale;
+                    b.y *= -(T)p.scale;
+                }
+                V* row = gout + (row0 + c) * p.out_pitch;
+                gstore<(C::NT & 2) != 0>(row + k, a);
+                if (2 * k != C::N) gstore<(C::NT & 2) != 0>(row + C::N - k, b);
             }
             __syncthreads();
         } else if constexpr (!C::LAST_DIRECT) {

@@ -165,3 +165,42 @@ def test_hermitian_twins_forced_on_small_shapes(shape, dtype, inverse, monkeypat
 
     small = np.prod(shape) <= 400000
     check_hermitian_plan(fft_fn, shape, dtype, inverse, oracle=O.fftn if small else None)
+
+
+@pytest.mark.parametrize("shape,dtype", [((3, 400, 96), np.float32), ((2, 300, 250), np.float32), ((2, 240, 96), np.float64),
+                                         ((1, 12, 200, 180), np.float32), ((25, 640, 480), np.float32)])  # (no plane fits LDS)
+@pytest.mark.parametrize("inverse", [False, True])
+def test_packed_real_rows_opt_in(shape, dtype, inverse, monkeypatch):
+    """MIFFT_R2C=1: the first pass of a real-input plan with a Hermitian last pass reads its rows of N reals as N / 2 packed
+    complex points and unpacks the half spectrum in its store loop (TileCfg::R2C).  Parity only: it is no faster than the tuned
+    half-store row kernels (DESIGN_EXPERIMENTS.md R3.8)."""
+    monkeypatch.setenv("MIFFT_HERM", "2")
+    monkeypatch.setenv("MIFFT_R2C", "1")
+    seen = []
+
+    def fft_fn(x, *, inverse, out_dtype):
+        out, plan = lab_fft(x, inverse=inverse)
+        seen.append([plan.kernel_name(d) for d in range(len(shape) - 1)])
+        return out, plan
+
+    check_hermitian_plan(fft_fn, shape, dtype, inverse, oracle=O.fftn if np.prod(shape) <= 400000 else None)
+    assert "_r2c_" in seen[0][-1], seen[0]
+
+
+def test_packed_real_rows_widen_integer_input(monkeypatch):
+    """... and with uint8 input: pairs of bytes widened as the packed row is loaded."""
+    monkeypatch.setenv("MIFFT_HERM", "2")
+    monkeypatch.setenv("MIFFT_R2C", "1")
+    mf = lab()
+    rng = np.random.default_rng(5)
+    shape = (3, 360, 64)
+    a = rng.integers(0, 255, size=shape + (1,)).astype(np.uint8)
+    x = torch.from_numpy(a).to("cuda:0")
+    out = torch.full(shape + (2,), float("nan"), dtype=torch.float32, device="cuda:0")
+    with mf.DeviceContext(0) as ctx:
+        plan = mf.plan_fft(x.dtype, torch.float32, tuple(x.shape), tuple(out.shape), ctx=ctx)
+        mf.fft(out, x, ctx, plan=plan)
+        ctx.synchronize()
+    assert "_r2c_" in plan.kernel_name(1) and plan.kernel_name(0).endswith(("_h", "_h_jit")), [plan.kernel_name(0), plan.kernel_name(1)]
+    truth = np.fft.fftn(a[..., 0].astype(np.float64), axes=(1, 2))
+    assert rel_l2(out.cpu().numpy(), from_complex(truth, np.float64)) < REL_L2_TOL_F32
