@@ -423,8 +423,11 @@ build_passes:
                 DimPass t = ps;
                 t.want_half = true;
                 t.store_lim = (int)(dims[2] / 2);
+                bool found = false;
+#ifdef MIFFT_EXPERIMENTAL  // packed real rows: a measured tie with the tuned half-store kernels, lab builds only
                 std::string whyr;
-                bool found = cfg.r2c_rows && select_jit_r2c(p, t, whyr);
+                found = cfg.r2c_rows && select_jit_r2c(p, t, whyr);
+#endif
                 if (!found) found = select_fast(p, t);
                 if (!found && ps.N <= 4096) {
                     DimPass u = ps;
@@ -449,8 +452,11 @@ build_passes:
                 DimPass t = ps;
                 t.want_half = true;
                 t.store_lim = (int)(dims[1] / 2);
+                bool found = false;
+#ifdef MIFFT_EXPERIMENTAL  // (2-D plans: this is the row pass)
                 std::string whyr;
-                bool found = cfg.r2c_rows && ps.first && select_jit_r2c(p, t, whyr);  // (2-D plans: this is the row pass)
+                found = cfg.r2c_rows && ps.first && select_jit_r2c(p, t, whyr);
+#endif
                 if (!found) found = select_fast(p, t);
                 if (!found && ps.N <= 4096) {
                     DimPass u = ps;

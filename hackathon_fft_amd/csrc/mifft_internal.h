@@ -198,7 +198,7 @@ bool select_dpp_rows(const Plan& plan, DimPass& pass);
 // the tile kernel specialised at plan time with hipRTC for a length without a table entry (kernels_jit.cpp)
 bool select_jit(const Plan& plan, DimPass& pass, std::string& why_not);
 // first pass over a REAL tensor whose last pass will be a Hermitian twin: rows read as N / 2 packed complex points, unpacked
-// into the half spectrum by the store loop (TileCfg::R2C); pass.want_half asks for it
+// into the half spectrum by the store loop (TileCfg::R2C); pass.want_half asks for it.  LAB BUILD ONLY.
 bool select_jit_r2c(const Plan& plan, DimPass& pass, std::string& why_not);
 // four-step helpers: the transposed + twiddled column pass (reads x: real / integer input allowed) and cheap
 // feasibility predicates for scoring factorisations without compiling
