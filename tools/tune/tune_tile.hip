@@ -59,6 +59,9 @@ Variant make(const char* name) {
         tp.tw = tw;
         tp.inverse = 0;
         tp.scale = 1.0;
+        tp.store_lim = C::N / 2;  // (HS variants)
+        tp.r2c_tw = tw;           // (R2C variants: timing only -- the table is the N-point one)
+        tp.out_pitch = 2 * C::N;
         if (C::COLS) {
             tp.inner = inner;
             tp.tiles_per_outer = (inner + C::TILE - 1) / C::TILE;
@@ -255,6 +258,10 @@ Variant make_plane_wp(const char* name) {
 #define VN(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, false, false, NT>>(NAME)
 // real input (C_in = 1) promoted in the pass-0 load: ... PF, then NT
 #define VR(NAME, NT, ...) make<TileCfg<__VA_ARGS__, 0, true, false, NT>>(NAME)
+// real input + half store (TileCfg::HS; store_lim = N / 2): the first pass in front of a Hermitian last pass
+#define VRH(NAME, NT, T, ...) make<TileCfg<T, __VA_ARGS__, 0, true, false, NT, false, T, false, false, 0, false, true>>(NAME)
+// packed real rows (TileCfg::R2C): N is HALF the row length; LAST_DIRECT must be false
+#define VRP(NAME, NT, T, ...) make<TileCfg<T, __VA_ARGS__, 0, false, false, NT, false, T, false, false, 0, false, false, true>>(NAME)
 // ... with an LDS row pad (ROWS: pitch = N + PAD)
 #define VNP(NAME, NT, PAD, ...) make<TileCfg<__VA_ARGS__, PAD, false, false, NT>>(NAME)
 // DMA-staged flat-copy rows: T N NP R0..R3 TILE THREADS TWMODE MINW
@@ -401,6 +408,27 @@ int main(int argc, char** argv) {
         VN("r480 10x6x8 t8 384 w2 nt1", 1, float, 480, 3, 10, 6, 8, 1, 8, 384, false, true, true, TW_LDS, 2, false),
         VN("r480 10x6x8 t16 512 w2 nt1", 1, float, 480, 3, 10, 6, 8, 1, 16, 512, false, true, true, TW_LDS, 2, false),
         VN("r480 6x8x10 t8 512 w2 nt1", 1, float, 480, 3, 6, 8, 10, 1, 8, 512, false, true, true, TW_LDS, 2, false),
+    };
+#elif GROUP == 27  // ---- real input, half store: 64000 rows of 480 (first pass of 100 x 640 x 480 real) ----
+    const long long batch = 64000, outer = 1, inner = 1;
+    const int N = 480;
+    std::vector<Variant> vs = {
+        VR("real full 10x6x8 t8 256 pf nt1", 1, float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+        VRH("hs 10x6x8 t8 256 pf nt1 (shipped)", 1, float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+        VRH("hs 10x6x8 t8 256 pf nt0", 0, float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+        VRH("hs 10x6x8 t8 256 nt1", 1, float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, true, TW_LDS, 2, false),
+        VRH("hs 10x6x8 t4 128 pf nt1", 1, float, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 2, true),
+        VRH("hs 10x6x8 t4 128 nt1", 1, float, 480, 3, 10, 6, 8, 1, 4, 128, false, true, true, TW_LDS, 2, false),
+        VRH("hs 10x6x8 t16 512 nt1", 1, float, 480, 3, 10, 6, 8, 1, 16, 512, false, true, true, TW_LDS, 2, false),
+        VRH("hs 8x6x10 t8 256 pf nt1", 1, float, 480, 3, 8, 6, 10, 1, 8, 256, false, true, true, TW_LDS, 2, true),
+        VRH("hs 4x4x5x6 t8 512 nt1", 1, float, 480, 4, 4, 4, 5, 6, 8, 512, false, true, true, TW_LDS, 2, false),
+        VRH("hs 6x5x4x4 t8 512 nt1", 1, float, 480, 4, 6, 5, 4, 4, 8, 512, false, true, true, TW_LDS, 2, false),
+        VRH("hs 16x30 t8 256 nt1", 1, float, 480, 2, 16, 30, 1, 1, 8, 256, false, true, true, TW_LDS, 2, false),
+        VRH("hs 10x6x8 t8 256 pf nt1 flat-store", 1, float, 480, 3, 10, 6, 8, 1, 8, 256, false, true, false, TW_LDS, 2, true),
+        VRP("r2c 15x8x2 t8 256 nt1", 1, float, 240, 3, 15, 8, 2, 1, 8, 256, false, true, false, TW_LDS, 2, false),
+        VRP("r2c 15x8x2 t8 256 pf nt1", 1, float, 240, 3, 15, 8, 2, 1, 8, 256, false, true, false, TW_LDS, 2, true),
+        VRP("r2c 16x15 t4 128 nt1", 1, float, 240, 2, 16, 15, 1, 1, 4, 128, false, true, false, TW_LDS, 2, false),
+        VRP("r2c 8x6x5 t16 256 nt1", 1, float, 240, 3, 8, 6, 5, 1, 16, 256, false, true, false, TW_LDS, 2, false),
     };
 #elif GROUP == 6  // ---- config 5 y / x axes: columns of 128 ----
     const long long batch = 10, outer = 128, inner = 128;  // y axis; x axis is outer 1, inner 16384
