@@ -159,7 +159,7 @@ inline long long herm_tiles_per_outer(const DimPass& pass, int tile) {
 //     every size when the rows of the trailing dimension are a whole number of tiles; ragged rows leave every mirrored line
 //     in pieces (6 x 360^3 +3 %) unless the tensor stays in the Infinity Cache, where the pieces merge;
 //   * narrower tiles (strided dimensions beyond ~1024 points) store every mirrored line in pieces: alone a gain (3-15 %) only
-//     while the tensor is cache resident, and none at all for the 2-column tiles of 3840-point columns;
+//     while the tensor is cache resident (with the table's own three-pass configurations: 4K frames 7-16 %);
 //   * with a half-store pass in front (plan.hs_selected: that pass skips half its writes) the ragged and the 4- / 8-column cases
 //     pay beyond the cache too: 40 x 1920 x 1080 0.98 -> 0.91, 6 x 360^3 1.03 -> 0.93, 300 x 600 x 500 1.02 -> 0.95;
 //   * a Hermitian tile stores twice what an ordinary one does, so half the tiles must also mean clearly fewer ROUNDS of the
@@ -173,7 +173,7 @@ inline bool herm_pays(const Plan& plan, const DimPass& pass, int tile, size_t ld
     const long long run_bytes = (long long)tile * (long long)plan.out_elem_bytes();
     if (run_bytes >= 128) {
         if (d2 % tile != 0 && !resident && !plan.hs_selected) return false;
-    } else if (run_bytes < 32 || pass.N > 2048 || !(resident || plan.hs_selected)) {
+    } else if (run_bytes < 32 || !(resident || plan.hs_selected)) {
         return false;
     }
     DimPass dims = pass;
