@@ -37,6 +37,7 @@ static int launch_tile(const Plan& plan, const DimPass& pass, const void* in, vo
             tp.tiles_per_outer = herm_tiles_per_outer(pass, C::TILE);
         } else if (pass.col_prefix > 0) {  // (middle pass of a half-spectrum schedule: only the columns that were stored)
             tp.tiles_per_outer = (pass.col_prefix + C::TILE - 1) / C::TILE;
+            tp.col_lim = pass.col_prefix;
         }
         tp.n_tiles = count * pass.outer * tp.tiles_per_outer;
     } else {

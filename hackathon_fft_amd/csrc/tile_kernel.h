@@ -137,6 +137,9 @@ struct TileParams {
     // R2C configurations: W_(2N)^k, k = 0 .. N (forward, whatever the plan's direction), and the row pitch of `out` (2 N)
     const void* r2c_tw;
     long long out_pitch;
+    // column tiles of a pass that transforms only a PREFIX of its column space (the middle pass of a half-spectrum schedule):
+    // columns from col_lim on are neither loaded nor stored (0 = all `inner` columns)
+    long long col_lim;
 };
 
 MIFFT_DEV long long tile_id(const TileParams& p, long long t) { return p.reverse ? p.n_tiles - 1 - t : t; }
@@ -500,7 +503,7 @@ MIFFT_DEV void tile_geom(const TileParams& p, long long t, long long& base, int&
     } else if constexpr (C::COLS) {
         const long long o = t / p.tiles_per_outer;
         const long long c0 = (t - o * p.tiles_per_outer) * C::TILE;
-        const long long left = p.inner - c0;
+        const long long left = (p.col_lim ? p.col_lim : p.inner) - c0;
         nv = (int)(left < C::TILE ? left : C::TILE);
         base = o * (long long)C::N * p.inner + c0;
     } else {
