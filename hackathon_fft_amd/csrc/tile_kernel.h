@@ -808,6 +808,9 @@ MIFFT_DEV void pass_compute_scatter(const TileParams& p, cpx<typename C::T>* lds
                     const long long step = (long long)P * elem_stride<C>(p);  // uniform
 #pragma unroll
                     for (int s = 0; s < R; ++s) {
+                        // (HS: store_lim is N / 2 and this is the last pass, o0 < P -- outputs s * P > N / 2 are never stored: a
+                        //  compile-time test per unrolled s, so the butterfly's unused results are not even computed)
+                        if (C::HS && s * P > C::N / 2) continue;
                         V y = v[k][s];
                         if (p.inverse) {
                             y.x *= (T)p.scale;
@@ -1745,6 +1748,7 @@ MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long
             const unsigned off = (unsigned)o0 * (unsigned)G::N2 + (unsigned)c;
 #pragma unroll
             for (int s = 0; s < R; ++s) {
+                if (CC::HS && s * P > CC::N / 2) continue;  // (never stored: not computed either, see pass_compute_scatter)
                 V y = v[k][s];
                 if (p.inverse) {
                     y.x *= (T)p.scale;
@@ -1792,6 +1796,7 @@ MIFFT_DEV void wp_col_passes(const TileParams& p, cpx<typename CR::T>* lds, long
                 const unsigned off = (unsigned)o0 * (unsigned)G::N2 + (unsigned)(wave * G::CPW + cl);
 #pragma unroll
                 for (int s = 0; s < R; ++s) {
+                    if (CC::HS && s * P > CC::N / 2) continue;
                     V y = v[k][s];
                     if (p.inverse) {
                         y.x *= (T)p.scale;
