@@ -19,6 +19,8 @@ fam = collections.Counter()
 fails = 0
 t_start = time.time()
 for i in range(cases):
+    if i and i % 100 == 0:  # (a run that prints nothing for minutes is taken to be hung)
+        print(f"... {i} cases, {fails} failures, {time.time() - t_start:.0f} s", flush=True)
     nd = int(rng.choice([1, 1, 1, 2, 2, 2, 3, 3, 4, 5]))
     if BIG:
         nd = int(rng.choice([2, 2, 3, 3, 4]))
