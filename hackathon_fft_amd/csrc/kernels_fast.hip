@@ -335,6 +335,10 @@ static const PlaneEntry kPlaneTable[] = {
      512, Plane64R::LDS_BYTES},
     {false, false, false, MIFFT_F32, 64, 64, "plane64x64_8x8", launch_plane<Plane64R, Plane64C>, prepare_plane<Plane64R, Plane64C>,
      512, Plane64R::LDS_BYTES},
+    // real input is not bound by its bytes (DESIGN_EXPERIMENTS.md R3.8): the wave-private exchanges, a tie for complex 64 x 64
+    // planes, win here -- 6400 real planes 0.0499 -> 0.0447 ms (tools/tune GROUP 28)
+    {false, false, true, MIFFT_F32, 64, 64, "plane64x64_8x8_wp_r_hs", launch_plane_wp<Plane64RR, Plane64CH, 8>,
+     prepare_plane_wp<Plane64RR, Plane64CH, 8>, 512, WavePlane<Plane64RR, Plane64CH, 8>::LDS_BYTES, true},
     {false, false, true, MIFFT_F32, 64, 64, "plane64x64_8x8_r_hs", launch_plane<Plane64RR, Plane64CH>, prepare_plane<Plane64RR, Plane64CH>,
      512, Plane64RR::LDS_BYTES, true},
     {false, false, true, MIFFT_F32, 64, 64, "plane64x64_8x8_r", launch_plane<Plane64RR, Plane64C>, prepare_plane<Plane64RR, Plane64C>,

@@ -188,6 +188,7 @@ Variant make_plane(const char* name) {
     v.lds = CR::LDS_BYTES;
     v.run = [](const void* in, void* out, const void* tw, long long batch, long long outer, long long inner) {
         TileParams tp{};
+        tp.store_lim = CC::N / 2;  // (HS column sides)
         tp.in = in;
         tp.out = out;
         tp.tw = tw;
@@ -216,6 +217,7 @@ Variant make_plane_wp(const char* name) {
     v.lds = G::LDS_BYTES;
     v.run = [](const void* in, void* out, const void* tw, long long batch, long long outer, long long inner) {
         TileParams tp{};
+        tp.store_lim = CC::N / 2;  // (HS column sides)
         tp.in = in;
         tp.out = out;
         tp.tw = tw;
@@ -282,6 +284,15 @@ Variant make_plane_wp(const char* name) {
     make_plane_wp<TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, false, true, false, TW_LDS, MINW, PF>,         \
                   TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, true, false, true, TW_LDS, MINW, false>, PAD, true>(NAME)
 
+// real input (rows side promotes) + half store (column side): the plane in front of a Hermitian last pass
+#define HSCOL(PN, NP, R0, R1, R2, R3, THR, MINW) \
+    TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, true, false, true, TW_LDS, MINW, false, 0, false, false, 0, false, float, false, false, 0, false, true>
+#define PLNR(NAME, PN, THR, MINW, PF, R0, R1, R2, R3, NP)                                                        \
+    make_plane<TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, false, true, false, TW_LDS, MINW, PF, 0, true>,   \
+               HSCOL(PN, NP, R0, R1, R2, R3, THR, MINW)>(NAME)
+#define PLWR(NAME, PN, PAD, THR, MINW, PF, R0, R1, R2, R3, NP)                                                   \
+    make_plane_wp<TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, false, true, false, TW_LDS, MINW, PF, 0, true>, \
+                  HSCOL(PN, NP, R0, R1, R2, R3, THR, MINW), PAD>(NAME)
 #define PLN(NAME, PN, THR, MINW, PF, R0, R1, R2, R3, NP)                                                         \
     make_plane<TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, false, true, false, TW_LDS, MINW, PF>,            \
                TileCfg<float, PN, NP, R0, R1, R2, R3, PN, THR, true, false, true, TW_LDS, MINW, false>>(NAME)
@@ -576,6 +587,23 @@ int main(int argc, char** argv) {
         PLW("wp64 8x8 256 w2 pf pad16", 64, 16, 256, 2, true, 8, 8, 1, 1, 2),
         PLW("wp64 8x8 256 w4 pad16", 64, 16, 256, 4, false, 8, 8, 1, 1, 2),
         PLW("wp64 4x4x4 512 w2 pf pad8", 64, 8, 512, 2, true, 4, 4, 4, 1, 3),
+    };
+#elif GROUP == 28  // ---- 100 x 64^3 REAL input: fused y+x planes with the half store, 6400 planes of 64x64 ----
+    const long long batch = 100, outer = 64, inner = 1;
+    const int N = 64;
+    std::vector<Variant> vs = {
+        PLNR("plane64 r hs 8x8 512 w2 (shipped)", 64, 512, 2, false, 8, 8, 1, 1, 2),
+        PLNR("plane64 r hs 8x8 512 w2 pf", 64, 512, 2, true, 8, 8, 1, 1, 2),
+        PLNR("plane64 r hs 8x8 256 w2", 64, 256, 2, false, 8, 8, 1, 1, 2),
+        PLNR("plane64 r hs 8x8 256 w4", 64, 256, 4, false, 8, 8, 1, 1, 2),
+        PLNR("plane64 r hs 4x4x4 512 w2", 64, 512, 2, false, 4, 4, 4, 1, 3),
+        PLNR("plane64 r hs 16x4 256 w2", 64, 256, 2, false, 16, 4, 1, 1, 2),
+        PLNR("plane64 r hs 8x8 1024 w4", 64, 1024, 4, false, 8, 8, 1, 1, 2),
+        PLWR("wp64 r hs 8x8 512 w2 pad8", 64, 8, 512, 2, false, 8, 8, 1, 1, 2),
+        PLWR("wp64 r hs 8x8 512 w2 pf pad8", 64, 8, 512, 2, true, 8, 8, 1, 1, 2),
+        PLWR("wp64 r hs 8x8 256 w2 pf pad16", 64, 16, 256, 2, true, 8, 8, 1, 1, 2),
+        PLWR("wp64 r hs 8x8 256 w4 pad16", 64, 16, 256, 4, false, 8, 8, 1, 1, 2),
+        PLWR("wp64 r hs 4x4x4 512 w2 pf pad8", 64, 8, 512, 2, true, 4, 4, 4, 1, 3),
     };
 #elif GROUP == 14  // ---- long rows: 3906 x 8192 ----
     const long long batch = 3906, outer = 1, inner = 1;
@@ -887,7 +915,7 @@ int main(int argc, char** argv) {
 #error "define GROUP"
 #endif
 
-#if GROUP == 7 || GROUP == 13
+#if GROUP == 7 || GROUP == 13 || GROUP == 28
     const size_t elems = (size_t)batch * outer * N * N;
 #else
     const size_t elems = (size_t)batch * outer * inner * N;
