@@ -605,6 +605,21 @@ int main(int argc, char** argv) {
         PLWR("wp64 r hs 8x8 256 w4 pad16", 64, 16, 256, 4, false, 8, 8, 1, 1, 2),
         PLWR("wp64 r hs 4x4x4 512 w2 pf pad8", 64, 8, 512, 2, true, 4, 4, 4, 1, 3),
     };
+#elif GROUP == 29  // ---- 10 x 128^3 REAL input: fused planes with the half store, 1280 planes of 128x128 ----
+    const long long batch = 10, outer = 128, inner = 1;
+    const int N = 128;
+    std::vector<Variant> vs = {
+        PLWR("wp r hs 8x16 1024 w4 pf pad8 (shipped)", 128, 8, 1024, 4, true, 8, 16, 1, 1, 2),
+        PLWR("wp r hs 8x16 1024 w4 pad8", 128, 8, 1024, 4, false, 8, 16, 1, 1, 2),
+        PLWR("wp r hs 16x8 1024 w4 pf pad8", 128, 8, 1024, 4, true, 16, 8, 1, 1, 2),
+        PLWR("wp r hs 8x4x4 1024 w4 pf pad8", 128, 8, 1024, 4, true, 8, 4, 4, 1, 3),
+        PLWR("wp r hs 4x4x8 1024 w4 pf pad8", 128, 8, 1024, 4, true, 4, 4, 8, 1, 3),
+        PLWR("wp r hs 8x16 512 w2 pf pad8", 128, 8, 512, 2, true, 8, 16, 1, 1, 2),
+        PLWR("wp r hs 16x8 512 w2 pf pad8", 128, 8, 512, 2, true, 16, 8, 1, 1, 2),
+        PLWR("wp r hs 8x16 1024 w4 pf pad0", 128, 0, 1024, 4, true, 8, 16, 1, 1, 2),
+        PLNR("plane r hs 8x16 1024 w4 pf", 128, 1024, 4, true, 8, 16, 1, 1, 2),
+        PLNR("plane r hs 16x8 1024 w4 pf", 128, 1024, 4, true, 16, 8, 1, 1, 2),
+    };
 #elif GROUP == 14  // ---- long rows: 3906 x 8192 ----
     const long long batch = 3906, outer = 1, inner = 1;
     const int N = 8192;
@@ -915,7 +930,7 @@ int main(int argc, char** argv) {
 #error "define GROUP"
 #endif
 
-#if GROUP == 7 || GROUP == 13 || GROUP == 28
+#if GROUP == 7 || GROUP == 13 || GROUP == 28 || GROUP == 29
     const size_t elems = (size_t)batch * outer * N * N;
 #else
     const size_t elems = (size_t)batch * outer * inner * N;
