@@ -29,6 +29,12 @@
 // compact conflict-free LDS table [pass][j][p] (TWMODE 2); TWMODE 0 reads the global table.
 // Inverse: conj(F(conj x)) * 1/N with the forward butterflies (bit-identical to conjugated
 // twiddles), reference semantics fft/fft/_utils.mojo:101-104, fft/fft/_fft.mojo:292-294.
+//
+// Real input, N-D plans (the reference computes the whole spectrum in every pass): the LAST pass may transform only the
+// columns that are not beyond their mirror image and store every result twice (TileCfg::HERM: contiguous runs of tiles, a
+// carried column so that mirrored lines leave whole); the pass in front of it stores only the half it reads (TileCfg::HS),
+// or -- three-pass plans -- the first pass does and the middle pass transforms a column prefix (TileParams::col_lim).
+// TileCfg::R2C (packed real rows) is a measured tie kept for the lab build.  Selection and policy: mifft_api.cpp, herm_pays().
 #pragma once
 
 #include "fft_radix.h"
